@@ -1,0 +1,461 @@
+"""CPU oracle for the per-output GP marginal-likelihood fitting path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  The product path (``waveome_amd``) never routes through this file
+and fails loudly when the HIP library is missing.
+
+What it restates (NumPy/SciPy float64, dense, O(N^3) via LAPACK):
+
+* the exact-GP log marginal likelihood the reference writes out in
+  ``waveome/model_types_DEPR.py:42-56`` (``K -> K + sigma^2 I -> cholesky ->
+  multivariate_normal``) and instantiates as ``gpflow.models.GPR`` in
+  ``waveome/model_fitting.py:150-155``;
+* the custom kernels of ``waveome/kernels.py`` (``Lin`` :5-39, ``Poly`` :42-83,
+  ``Categorical`` :86-124, ``Empty`` :127-142) and the GPflow 2.9.1 kernels the
+  reference composes with them (``regularization.py:23,112,139,166,181``):
+  SquaredExponential, Matern12/32/52, Periodic(SquaredExponential), Constant,
+  Sum, Product;
+* the objective wiring of ``waveome/model_classes.py:817-864``: training loss
+  ``-(LML + sum log Horseshoe(variance; scale=1/pf))`` over *trainable* kernel
+  variance parameters, prior on the constrained value, no Jacobian;
+* GPflow's parameter transforms (Softplus for positive parameters,
+  Softplus + Shift(1e-6) for the Gaussian likelihood variance, identity for the
+  Constant mean) and the SciPy ``L-BFGS-B`` call of
+  ``waveome/model_classes.py:299-342`` (``gpflow.optimizers.Scipy().minimize``).
+
+Third-party arithmetic (GPflow 2.9.1, TensorFlow-Probability 0.20-0.23, SciPy)
+is not vendored under /root/reference and is absent from this image, so the
+formulas below restate the published algorithms.  Pinning status:
+
+* PINNED by the reference's own stored notebook outputs (tests/golden/kat.json):
+  SquaredExponential value+optimum (KAT-1, 13 s.f.), Matern52 optimum (KAT-2),
+  Matern12 optimum to 2 dp (KAT-3), Softplus / Softplus+Shift transforms,
+  the LML formula, GPflow default initial values.
+* PARITY UNPINNED (no known answer anywhere in the reference): Matern32,
+  Periodic, Categorical, Lin, Poly, Sum/Product composites, the Constant mean,
+  and the Horseshoe log-density.  They are checked by finite differences and
+  algebraic identities only (tests/test_oracle.py).
+
+Kernel-spec format (plain data, shared with the product's encoder only as a
+dict so the oracle imports nothing from the product):
+
+    spec = {
+      "D": int,
+      "params": [{"name": str, "init": float, "transform": "softplus" |
+                  "softplus_shift" | "identity", "trainable": bool,
+                  "prior_scale": float | None}, ...],
+      "terms": [[factor, ...], ...],          # K = sum_t prod_f k_f
+      "noise": int,                           # index into params
+      "mean": int | None,                     # Constant mean c
+    }
+    factor = {"type": "se"|"m12"|"m32"|"m52"|"periodic"|"lin"|"poly"|"const"|
+                      "cat"|"empty",
+              "dims": [int, ...], "p": [param indices ...], "degree": int}
+    param order inside "p": se/m12/m32/m52 -> [variance, lengthscales];
+    periodic -> [variance, lengthscales, period]; lin/const/cat -> [variance];
+    poly -> [variance, offset]; empty -> [].
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.linalg
+import scipy.optimize
+
+NOISE_FLOOR = 1e-6  # GPflow Gaussian likelihood DEFAULT_VARIANCE_LOWER_BOUND [3P]
+LOG_2PI = math.log(2.0 * math.pi)
+SQRT3 = math.sqrt(3.0)
+SQRT5 = math.sqrt(5.0)
+
+
+# --------------------------------------------------------------------------
+# transforms (GPflow `positive()` = Softplus; likelihood variance = Softplus+Shift)
+# --------------------------------------------------------------------------
+def softplus(u):
+    u = np.asarray(u, dtype=np.float64)
+    return np.logaddexp(0.0, u)
+
+
+def inv_softplus(x):
+    x = np.asarray(x, dtype=np.float64)
+    # log(expm1(x)) written to stay finite for large x
+    return x + np.log(-np.expm1(-x))
+
+
+def sigmoid(u):
+    u = np.asarray(u, dtype=np.float64)
+    return 0.5 * (1.0 + np.tanh(0.5 * u))
+
+
+def constrain_one(kind, u):
+    if kind == "softplus":
+        return float(softplus(u))
+    if kind == "softplus_shift":
+        return float(NOISE_FLOOR + softplus(u))
+    if kind == "identity":
+        return float(u)
+    raise ValueError(kind)
+
+
+def unconstrain_one(kind, x):
+    if kind == "softplus":
+        return float(inv_softplus(x))
+    if kind == "softplus_shift":
+        return float(inv_softplus(x - NOISE_FLOOR))
+    if kind == "identity":
+        return float(x)
+    raise ValueError(kind)
+
+
+def dconstrain_one(kind, u):
+    if kind in ("softplus", "softplus_shift"):
+        return float(sigmoid(u))
+    return 1.0
+
+
+def trainable_index(spec):
+    return [i for i, p in enumerate(spec["params"]) if p["trainable"]]
+
+
+def theta_init(spec):
+    return np.array([p["init"] for p in spec["params"]], dtype=np.float64)
+
+
+def pack_u(spec, theta):
+    """constrained full vector -> unconstrained trainable vector."""
+    return np.array(
+        [unconstrain_one(spec["params"][i]["transform"], theta[i]) for i in trainable_index(spec)],
+        dtype=np.float64,
+    )
+
+
+def unpack_u(spec, u, theta_base=None):
+    """unconstrained trainable vector -> constrained full vector."""
+    theta = theta_init(spec) if theta_base is None else np.array(theta_base, dtype=np.float64)
+    for k, i in enumerate(trainable_index(spec)):
+        theta[i] = constrain_one(spec["params"][i]["transform"], u[k])
+    return theta
+
+
+# --------------------------------------------------------------------------
+# base kernels: value and d/d(param) on dense (N, N2) grids
+# --------------------------------------------------------------------------
+def _sqdist(X, X2, dims):
+    r2 = np.zeros((X.shape[0], X2.shape[0]))
+    for d in dims:
+        diff = X[:, d][:, None] - X2[:, d][None, :]
+        r2 += diff * diff
+    return r2
+
+
+def factor_value_and_grads(f, theta, X, X2=None):
+    """Return (k, [dk/dparam for param in f['p']]) as dense arrays.
+
+    Formulas: SURVEY.md Appendix A; custom kernels waveome/kernels.py:19-32
+    (Lin), :56-73 (Poly), :95-117 (Categorical), :136-139 (Empty)."""
+    if X2 is None:
+        X2 = X
+    t = f["type"]
+    dims = f["dims"]
+    p = [theta[i] for i in f["p"]]
+    shape = (X.shape[0], X2.shape[0])
+    if t == "se":
+        var, ell = p
+        r2 = _sqdist(X, X2, dims)
+        e = np.exp(-0.5 * r2 / (ell * ell))
+        return var * e, [e, var * e * r2 / ell**3]
+    if t in ("m12", "m32", "m52"):
+        var, ell = p
+        r = np.sqrt(_sqdist(X, X2, dims))
+        s = r / ell
+        if t == "m12":
+            e = np.exp(-s)
+            return var * e, [e, var * e * s / ell]
+        if t == "m32":
+            e = np.exp(-SQRT3 * s)
+            g = (1.0 + SQRT3 * s) * e
+            return var * g, [g, var * 3.0 * s * s * e / ell]
+        e = np.exp(-SQRT5 * s)
+        g = (1.0 + SQRT5 * s + (5.0 / 3.0) * s * s) * e
+        return var * g, [g, var * (5.0 / 3.0) * s * s * (1.0 + SQRT5 * s) * e / ell]
+    if t == "periodic":
+        # gpflow.kernels.Periodic(SquaredExponential): r = pi (x-x')/p,
+        # k = var * exp(-0.5 * sum_d (sin(r_d)/ell)^2)  [3P]
+        var, ell, per = p
+        s2 = np.zeros(shape)
+        sc = np.zeros(shape)  # sum_d d_d * sin(r_d) cos(r_d)
+        for d in dims:
+            diff = X[:, d][:, None] - X2[:, d][None, :]
+            r = np.pi * diff / per
+            sn = np.sin(r)
+            s2 += sn * sn
+            sc += diff * sn * np.cos(r)
+        e = np.exp(-0.5 * s2 / (ell * ell))
+        k = var * e
+        return k, [e, k * s2 / ell**3, k * np.pi * sc / (per * per * ell * ell)]
+    if t == "lin":
+        (var,) = p
+        xx = np.zeros(shape)
+        for d in dims:
+            xx += X[:, d][:, None] * X2[:, d][None, :]
+        return var * xx, [xx]
+    if t == "poly":
+        var, off = p
+        deg = int(f["degree"])
+        xx = np.zeros(shape)
+        for d in dims:
+            xx += X[:, d][:, None] * X2[:, d][None, :]
+        base = var * xx + off
+        dk = deg * base ** (deg - 1)
+        return base**deg, [dk * xx, dk]
+    if t == "const":
+        (var,) = p
+        one = np.ones(shape)
+        return var * one, [one]
+    if t == "cat":
+        (var,) = p
+        d = dims[0]
+        # tf.round = round-half-to-even = np.rint; compared as int64
+        a = np.rint(X[:, d]).astype(np.int64)
+        b = np.rint(X2[:, d]).astype(np.int64)
+        m = (a[:, None] == b[None, :]).astype(np.float64)
+        return var * m, [m]
+    if t == "empty":
+        return np.zeros(shape), []
+    raise ValueError(f"unknown factor type {t!r}")
+
+
+def gram(spec, theta, X, X2=None):
+    """K = sum_t prod_f k_f  (gpflow Sum / Product, regularization.py:112,139,166,181)."""
+    X = np.asarray(X, dtype=np.float64)
+    X2 = X if X2 is None else np.asarray(X2, dtype=np.float64)
+    K = np.zeros((X.shape[0], X2.shape[0]))
+    for term in spec["terms"]:
+        prod = np.ones_like(K)
+        for f in term:
+            k, _ = factor_value_and_grads(f, theta, X, X2)
+            prod = prod * k
+        K += prod
+    return K
+
+
+def gram_param_grads(spec, theta, X):
+    """dict param_index -> dK/dtheta_p (dense). Parameters shared between factors add up."""
+    X = np.asarray(X, dtype=np.float64)
+    out = {}
+    for term in spec["terms"]:
+        vals = [factor_value_and_grads(f, theta, X) for f in term]
+        for gi, f in enumerate(term):
+            others = np.ones((X.shape[0], X.shape[0]))
+            for fi, (k, _) in enumerate(vals):
+                if fi != gi:
+                    others = others * k
+            for pi, dk in zip(f["p"], vals[gi][1]):
+                out[pi] = out.get(pi, 0.0) + others * dk
+    return out
+
+
+# --------------------------------------------------------------------------
+# exact log marginal likelihood (model_types_DEPR.py:49-56) and gradient
+# --------------------------------------------------------------------------
+def _resid(spec, theta, y):
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    return np.asarray(y, dtype=np.float64).reshape(-1) - c
+
+
+def lml(spec, theta, X, y):
+    """log N(y | c, K + sigma^2 I) = -1/2 |L^-1 r|^2 - sum log L_ii - N/2 log 2 pi."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    Ky = gram(spec, theta, X)
+    Ky[np.diag_indices(N)] += theta[spec["noise"]]
+    L = np.linalg.cholesky(Ky)
+    z = scipy.linalg.solve_triangular(L, _resid(spec, theta, y), lower=True)
+    return float(-0.5 * z @ z - np.sum(np.log(np.diag(L))) - 0.5 * N * LOG_2PI)
+
+
+def lml_and_grad(spec, theta, X, y):
+    """(LML, dLML/dtheta over ALL params, constrained coordinates).
+
+    dLML/dtheta_p = 1/2 tr(W dK/dtheta_p), W = alpha alpha^T - Ky^-1;
+    dLML/dsigma^2 = 1/2 tr(W); dLML/dc = 1^T alpha  (SURVEY.md Appendix A)."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    Ky = gram(spec, theta, X)
+    Ky[np.diag_indices(N)] += theta[spec["noise"]]
+    L = np.linalg.cholesky(Ky)
+    r = _resid(spec, theta, y)
+    z = scipy.linalg.solve_triangular(L, r, lower=True)
+    alpha = scipy.linalg.solve_triangular(L, z, lower=True, trans="T")
+    Kinv = scipy.linalg.cho_solve((L, True), np.eye(N))
+    W = np.outer(alpha, alpha) - Kinv
+    val = float(-0.5 * z @ z - np.sum(np.log(np.diag(L))) - 0.5 * N * LOG_2PI)
+    g = np.zeros(len(spec["params"]))
+    for pi, dK in gram_param_grads(spec, theta, X).items():
+        g[pi] += 0.5 * np.sum(W * dK)
+    g[spec["noise"]] += 0.5 * np.trace(W)
+    if spec.get("mean") is not None:
+        g[spec["mean"]] += np.sum(alpha)
+    return val, g
+
+
+# --------------------------------------------------------------------------
+# Horseshoe log-density: TFP `Horseshoe._log_prob` [3P, restated from the
+# published approximation; PARITY UNPINNED - no stored value in the reference].
+# Call site: waveome/model_classes.py:857-859 (scale = 1/penalization_factor).
+# --------------------------------------------------------------------------
+_HS_G = 0.5614594835668851  # exp(-EulerGamma)
+_HS_B = 1.0420764938351215  # sqrt(2 (1-g) / (g (2-g)))
+_HS_HINF = 1.0801359952503342  # (1-g)(g^2-6g+12) / (3 g (2-g)^2 b)
+_HS_POW = 1.0919284281983377
+
+
+def horseshoe_logpdf(x, scale):
+    x = float(x)
+    g, b, h_inf = _HS_G, _HS_B, _HS_HINF
+    xx = (x / scale) ** 2 / 2.0
+    q = 20.0 / 47.0 * xx**_HS_POW
+    h = 1.0 / (1.0 + xx**1.5) + h_inf * q / (1.0 + q)
+    c = -0.5 * math.log(2.0 * math.pi**3) - math.log(g * scale)
+    z = math.log1p(-g) - math.log(g)
+    sp = float(np.logaddexp(0.0, z - xx / (1.0 - g)))
+    return -sp + math.log(math.log1p(g / xx - (1.0 - g) / (h + b * xx) ** 2)) + c
+
+
+def horseshoe_dlogpdf(x, scale):
+    """d/dx of horseshoe_logpdf (analytic)."""
+    x = float(x)
+    g, b, h_inf = _HS_G, _HS_B, _HS_HINF
+    xx = (x / scale) ** 2 / 2.0
+    dxx = x / (scale * scale)
+    q = 20.0 / 47.0 * xx**_HS_POW
+    dq = 20.0 / 47.0 * _HS_POW * xx ** (_HS_POW - 1.0)
+    h = 1.0 / (1.0 + xx**1.5) + h_inf * q / (1.0 + q)
+    dh = -1.5 * math.sqrt(xx) / (1.0 + xx**1.5) ** 2 + h_inf * dq / (1.0 + q) ** 2
+    z = math.log1p(-g) - math.log(g)
+    t = z - xx / (1.0 - g)
+    # d/dxx of -softplus(t) = sigmoid(t) / (1-g)
+    d1 = float(sigmoid(t)) / (1.0 - g)
+    den = h + b * xx
+    inner = g / xx - (1.0 - g) / den**2
+    dinner = -g / (xx * xx) + 2.0 * (1.0 - g) * (dh + b) / den**3
+    l1p = math.log1p(inner)
+    d2 = dinner / ((1.0 + inner) * l1p)
+    return (d1 + d2) * dxx
+
+
+def log_prior(spec, theta):
+    """sum over trainable params carrying a Horseshoe prior (model_classes.py:862-864)."""
+    tot = 0.0
+    for i, p in enumerate(spec["params"]):
+        if p["trainable"] and p.get("prior_scale") is not None:
+            tot += horseshoe_logpdf(theta[i], p["prior_scale"])
+    return tot
+
+
+def log_prior_grad(spec, theta):
+    g = np.zeros(len(spec["params"]))
+    for i, p in enumerate(spec["params"]):
+        if p["trainable"] and p.get("prior_scale") is not None:
+            g[i] = horseshoe_dlogpdf(theta[i], p["prior_scale"])
+    return g
+
+
+# --------------------------------------------------------------------------
+# training loss in unconstrained coordinates and the SciPy L-BFGS-B fit
+# (gpflow `training_loss = -(maximum_log_likelihood_objective + log_prior_density)`,
+#  gpflow.optimizers.Scipy -> scipy.optimize.minimize(jac=True, method="L-BFGS-B"))
+# --------------------------------------------------------------------------
+def objective(spec, u, X, y):
+    """(loss, dloss/du) with loss = -(LML + log prior); u = unconstrained trainables."""
+    theta = unpack_u(spec, u)
+    try:
+        val, g = lml_and_grad(spec, theta, X, y)
+    except np.linalg.LinAlgError:
+        return np.inf, np.zeros_like(u)
+    val += log_prior(spec, theta)
+    g = g + log_prior_grad(spec, theta)
+    idx = trainable_index(spec)
+    gu = np.array(
+        [g[i] * dconstrain_one(spec["params"][i]["transform"], u[k]) for k, i in enumerate(idx)]
+    )
+    return -val, -gu
+
+
+def fit(spec, X, y, maxiter=50000, maxfun=None, ftol=2.220446049250313e-09, gtol=1e-05, maxcor=10,
+        maxls=20, u0=None, callback=None):
+    """SciPy L-BFGS-B from GPflow defaults; returns dict(theta, u, loss, lml, nit, nfev).
+
+    maxiter/maxfun = 50000 mirrors waveome/model_classes.py:310-313."""
+    if u0 is None:
+        u0 = pack_u(spec, theta_init(spec))
+    res = scipy.optimize.minimize(
+        lambda u: objective(spec, u, X, y),
+        u0,
+        jac=True,
+        method="L-BFGS-B",
+        callback=callback,
+        options={"maxiter": maxiter, "maxfun": maxfun or maxiter, "ftol": ftol, "gtol": gtol,
+                 "maxcor": maxcor, "maxls": maxls},
+    )
+    theta = unpack_u(spec, res.x)
+    return {
+        "theta": theta,
+        "u": res.x,
+        "loss": float(res.fun),
+        "lml": lml(spec, theta, X, y),
+        "nit": int(res.nit),
+        "nfev": int(res.nfev),
+        "status": int(res.status),
+        "message": str(res.message),
+    }
+
+
+# --------------------------------------------------------------------------
+# small spec builders used by tests / bench (GPflow defaults: all ones, c = 0)
+# --------------------------------------------------------------------------
+def make_spec(D, terms, mean=True, noise_init=1.0, prior_scale=None):
+    """terms: list of list of (type, dims[, opts]) tuples.
+
+    opts: {"freeze_variance": bool, "degree": int, "init": [..]}.
+    Kernel variance parameters get the Horseshoe prior when prior_scale is given and
+    they are trainable (model_classes.py:862-864: name contains 'kernel' and 'variance')."""
+    params = []
+    out_terms = []
+    npar = {"se": 2, "m12": 2, "m32": 2, "m52": 2, "periodic": 3, "lin": 1, "poly": 2, "const": 1,
+            "cat": 1, "empty": 0}
+    names = {"se": ["variance", "lengthscales"], "m12": ["variance", "lengthscales"],
+             "m32": ["variance", "lengthscales"], "m52": ["variance", "lengthscales"],
+             "periodic": ["base_kernel.variance", "base_kernel.lengthscales", "period"],
+             "lin": ["variance"], "poly": ["variance", "offset"], "const": ["variance"],
+             "cat": ["variance"], "empty": []}
+    for ti, term in enumerate(terms):
+        ft = []
+        for fi, fac in enumerate(term):
+            typ, dims = fac[0], list(fac[1])
+            opts = fac[2] if len(fac) > 2 else {}
+            idx = []
+            for k in range(npar[typ]):
+                nm = f"kernel.kernels[{ti}].kernels[{fi}].{names[typ][k]}"
+                is_var = names[typ][k].endswith("variance")
+                trainable = not (is_var and opts.get("freeze_variance", False))
+                init = opts.get("init", [1.0] * npar[typ])[k]
+                params.append({
+                    "name": nm, "init": float(init), "transform": "softplus", "trainable": trainable,
+                    "prior_scale": (prior_scale if (is_var and trainable) else None),
+                })
+                idx.append(len(params) - 1)
+            ft.append({"type": typ, "dims": dims, "p": idx, "degree": int(opts.get("degree", 3))})
+        out_terms.append(ft)
+    params.append({"name": "likelihood.variance", "init": float(noise_init),
+                   "transform": "softplus_shift", "trainable": True, "prior_scale": None})
+    noise = len(params) - 1
+    mean_idx = None
+    if mean:
+        params.append({"name": "mean_function.c", "init": 0.0, "transform": "identity",
+                       "trainable": True, "prior_scale": None})
+        mean_idx = len(params) - 1
+    return {"D": int(D), "params": params, "terms": out_terms, "noise": noise, "mean": mean_idx}

@@ -1,0 +1,197 @@
+"""Pins the CPU oracle: reference known answers (KAT-1/2/3 from the reference's notebooks),
+finite-difference gradients for every kernel type, algebraic identities, Horseshoe checks."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.integrate
+
+from oracle import gp_oracle as o
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "kat.json")) as fh:
+        return json.load(fh)
+
+
+def _kat_problem(c):
+    X = np.array(c["X"]).reshape(-1, 1)
+    Y = np.array(c["Y"])
+    spec = o.make_spec(1, [[(c["kernel"], [0])]], mean=False)
+    return spec, X, Y
+
+
+def test_kat1_value_at_printed_params(kat):
+    c = kat["kat1"]
+    spec, X, Y = _kat_problem(c)
+    e = c["expected"]
+    th = np.array([e["variance"], e["lengthscales"], e["noise"]])
+    # params are printed to 6 s.f.; LML is flat at the optimum so it agrees to ~1e-11 rel
+    assert o.lml(spec, th, X, Y) == pytest.approx(e["lml"], rel=5e-11)
+
+
+def test_kat1_fit_reproduces_notebook(kat):
+    c = kat["kat1"]
+    spec, X, Y = _kat_problem(c)
+    r = o.fit(spec, X, Y, maxiter=100)
+    e = c["expected"]
+    assert r["lml"] == pytest.approx(e["lml"], rel=1e-12)
+    assert r["theta"][0] == pytest.approx(e["variance"], rel=5e-6)
+    assert r["theta"][1] == pytest.approx(e["lengthscales"], rel=5e-6)
+    assert r["theta"][2] == pytest.approx(e["noise"], rel=5e-6)
+
+
+def test_kat2_matern52_fit(kat):
+    c = kat["kat2"]
+    spec, X, Y = _kat_problem(c)
+    r = o.fit(spec, X, Y, maxiter=100)
+    e = c["expected"]
+    assert r["theta"][0] == pytest.approx(e["variance"], rel=5e-6)
+    assert r["theta"][1] == pytest.approx(e["lengthscales"], rel=5e-6)
+    assert r["theta"][2] == pytest.approx(e["noise"], rel=5e-6)
+
+
+def test_kat3_matern12_two_decimals(kat):
+    c = kat["kat3"]
+    spec, X, Y = _kat_problem(c)
+    r = o.fit(spec, X, Y, maxiter=100)
+    assert abs(r["lml"] - c["expected"]["lml_2dp"]) < 0.01
+
+
+def test_transforms_roundtrip():
+    for x in [1e-8, 1e-3, 0.5, 1.0, 7.0, 50.0, 800.0]:
+        assert o.softplus(o.inv_softplus(x)) == pytest.approx(x, rel=1e-12)
+    assert o.constrain_one("softplus_shift", o.unconstrain_one("softplus_shift", 1.0)) == pytest.approx(1.0)
+    assert o.constrain_one("softplus_shift", -800.0) == pytest.approx(1e-6)
+
+
+def _rand_problem(seed, N=40, D=4):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, D))
+    X[:, 3] = rng.integers(0, 3, N).astype(float)
+    y = np.sin(X[:, 0]) + 0.3 * X[:, 1] + 0.5 * (X[:, 3] == 1) + 0.1 * rng.normal(size=N)
+    return X, y
+
+
+ALL_TERMS = [
+    [[("se", [0])]],
+    [[("se", [0, 1, 2])]],
+    [[("m12", [1])]],
+    [[("m32", [1])]],
+    [[("m52", [0, 1])]],
+    [[("periodic", [0])]],
+    [[("lin", [2])]],
+    [[("poly", [2], {"degree": 3})]],
+    [[("const", [0])]],
+    [[("cat", [3])]],
+    [[("cat", [3])], [("se", [0])], [("se", [1])], [("cat", [3], {"freeze_variance": True}), ("se", [0])],
+     [("cat", [3], {"freeze_variance": True}), ("periodic", [1])]],
+    [[("se", [0]), ("m32", [1])], [("lin", [2]), ("periodic", [0])], [("empty", [0])]],
+]
+
+
+@pytest.mark.parametrize("terms", ALL_TERMS)
+def test_gradient_matches_finite_differences(terms):
+    X, y = _rand_problem(3)
+    spec = o.make_spec(4, terms, mean=True, prior_scale=1.0)
+    rng = np.random.default_rng(5)
+    u = o.pack_u(spec, o.theta_init(spec)) + 0.3 * rng.normal(size=len(o.trainable_index(spec)))
+    f0, g0 = o.objective(spec, u, X, y)
+    for k in range(len(u)):
+        h = 1e-6
+        up, um = u.copy(), u.copy()
+        up[k] += h
+        um[k] -= h
+        fd = (o.objective(spec, up, X, y)[0] - o.objective(spec, um, X, y)[0]) / (2 * h)
+        assert g0[k] == pytest.approx(fd, rel=2e-6, abs=2e-7), (k, spec["params"][o.trainable_index(spec)[k]]["name"])
+
+
+def test_gram_symmetric_psd_and_sum_product_algebra():
+    X, _ = _rand_problem(7)
+    a = o.make_spec(4, [[("se", [0])]])
+    b = o.make_spec(4, [[("m32", [1])]])
+    ab = o.make_spec(4, [[("se", [0])], [("m32", [1])]])
+    axb = o.make_spec(4, [[("se", [0]), ("m32", [1])]])
+    Ka = o.gram(a, o.theta_init(a), X)
+    Kb = o.gram(b, o.theta_init(b), X)
+    np.testing.assert_allclose(o.gram(ab, o.theta_init(ab), X), Ka + Kb, rtol=1e-15)
+    np.testing.assert_allclose(o.gram(axb, o.theta_init(axb), X), Ka * Kb, rtol=1e-15)
+    np.testing.assert_array_equal(Ka, Ka.T)
+    assert np.linalg.eigvalsh(Ka + 1e-6 * np.eye(len(X))).min() > 0
+
+
+def test_categorical_equals_lin_on_one_hot():
+    # waveome/kernels.py:95-117 Categorical == sum of Lin kernels over one-hot columns
+    X, _ = _rand_problem(9)
+    cat = o.make_spec(4, [[("cat", [3])]])
+    Kc = o.gram(cat, o.theta_init(cat), X)
+    onehot = np.stack([(np.rint(X[:, 3]) == c).astype(float) for c in range(3)], axis=1)
+    np.testing.assert_array_equal(Kc, onehot @ onehot.T)
+
+
+def test_categorical_rounds_half_to_even():
+    X = np.array([[0.5], [1.5], [2.5], [0.0], [2.0]])
+    cat = o.make_spec(1, [[("cat", [0])]])
+    K = o.gram(cat, o.theta_init(cat), X)
+    # rint: 0.5->0, 1.5->2, 2.5->2
+    assert K[0, 3] == 1 and K[1, 4] == 1 and K[2, 4] == 1 and K[0, 1] == 0
+
+
+def test_periodic_tends_to_se_for_long_period():
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-1, 1, size=(30, 1))
+    per = o.make_spec(1, [[("periodic", [0])]])
+    se = o.make_spec(1, [[("se", [0])]])
+    P = 1e4
+    thp = o.theta_init(per)
+    thp[1] = 1.0 * np.pi / P  # sin(pi d/p)/ell ~ d * (pi/p) / ell -> ell_se = ell*p/pi
+    thp[2] = P
+    Kp = o.gram(per, thp, X)
+    Ks = o.gram(se, o.theta_init(se), X)
+    np.testing.assert_allclose(Kp, Ks, rtol=1e-6)  # limit error ~ (pi d/p)^2/6
+
+
+def test_lml_matches_scipy_multivariate_normal():
+    from scipy.stats import multivariate_normal
+
+    X, y = _rand_problem(11, N=25)
+    spec = o.make_spec(4, [[("se", [0])], [("cat", [3])]])
+    th = o.theta_init(spec)
+    th[spec["mean"]] = 0.3
+    Ky = o.gram(spec, th, X) + th[spec["noise"]] * np.eye(25)
+    ref = multivariate_normal(mean=np.full(25, 0.3), cov=Ky).logpdf(y)
+    assert o.lml(spec, th, X, y) == pytest.approx(ref, rel=1e-12)
+
+
+def test_horseshoe_bounds_and_integral():
+    # Carvalho-Polson-Scott bounds: (K/2) log(1+4/x^2) < p(x) < K log(1+2/x^2), K = (2 pi^3)^-1/2
+    Kc = 1.0 / math.sqrt(2.0 * math.pi**3)
+    for x in [1e-3, 0.05, 0.3, 1.0, 2.5, 10.0, 80.0]:
+        p = math.exp(o.horseshoe_logpdf(x, 1.0))
+        assert Kc / 2 * math.log1p(4 / x**2) < p < Kc * math.log1p(2 / x**2)
+        # exact marginal: int_0^inf N(x|0,lam^2) 2/(pi(1+lam^2)) dlam
+        f = lambda lam: math.exp(-0.5 * (x / lam) ** 2) / (lam * math.sqrt(2 * math.pi)) * 2 / (math.pi * (1 + lam * lam))
+        exact = scipy.integrate.quad(f, 0, np.inf, limit=400)[0]
+        assert p == pytest.approx(exact, rel=2e-3)
+    # scale family: p(x; s) = p(x/s; 1)/s
+    assert o.horseshoe_logpdf(0.7, 0.25) == pytest.approx(o.horseshoe_logpdf(2.8, 1.0) - math.log(0.25), rel=1e-13)
+
+
+def test_horseshoe_derivative():
+    for s in [1.0, 0.1, 4.0]:
+        for x in [1e-2, 0.3, 1.0, 5.0]:
+            h = 1e-6 * x
+            fd = (o.horseshoe_logpdf(x + h, s) - o.horseshoe_logpdf(x - h, s)) / (2 * h)
+            assert o.horseshoe_dlogpdf(x, s) == pytest.approx(fd, rel=1e-6)
+
+
+def test_non_pd_reports_inf():
+    X = np.zeros((5, 1))
+    spec = o.make_spec(1, [[("lin", [0])]], mean=False)
+    u = o.pack_u(spec, o.theta_init(spec))
+    u[-1] = -1e6  # noise -> floor 1e-6, K = 0 -> still PD (1e-6 I); make it fail with NaN input
+    f, _ = o.objective(spec, u, X, np.ones(5))
+    assert np.isfinite(f)
