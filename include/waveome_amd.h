@@ -1,0 +1,225 @@
+/* waveome_amd.h - C-ABI of the MI355X-native GP fitting core.
+ *
+ * Drop-in boundary for ONE path of omicsEye/waveome: the per-output Gaussian
+ * marginal-likelihood optimisation that `GPSearch.penalized_optimization()`
+ * runs per Y column (reference waveome/model_search.py:197-517).  The reference
+ * has no FFI of its own (it is pure Python over GPflow/TensorFlow); each entry
+ * point below names the reference interface it replaces.  INTEGRATION.md shows
+ * the ctypes stub a waveome maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types.
+ *   - matrices are row-major, contiguous, float64.
+ *   - X is N x D.  Y is P x N ("one contiguous row per output column").
+ *   - the caller owns every host buffer; the library copies X / Y to the device
+ *     at problem creation and owns all device memory.
+ *   - return value 0 = WV_OK, negative = WV_E_*; wv_last_error() gives a
+ *     thread-local message.  Numerical failure of ONE fit (non-PD Gram matrix)
+ *     is not an error: it is reported per task in status arrays and the
+ *     objective is +inf (the reference lets TF raise InvalidArgumentError and
+ *     retries, waveome/model_classes.py:323-340).
+ *   - a wv_ctx is re-entrant against other contexts, not thread-safe within
+ *     one context.  No device allocation happens inside wv_value_grad / wv_fit.
+ */
+#ifndef WAVEOME_AMD_H
+#define WAVEOME_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WV_ABI_VERSION 1
+
+typedef struct wv_ctx wv_ctx;
+typedef struct wv_problem wv_problem;
+typedef struct wv_lbfgs wv_lbfgs;
+
+enum {
+  WV_OK = 0,
+  WV_E_BADARG = -1,   /* null pointer, size out of range */
+  WV_E_SPEC = -2,     /* malformed kernel spec */
+  WV_E_NODEVICE = -3, /* no gfx950 device visible */
+  WV_E_HIP = -4,      /* HIP runtime error (message in wv_last_error) */
+  WV_E_OOM = -5,      /* device allocation failed */
+  WV_E_UNSUPPORTED = -6
+};
+
+/* Factor types.  Formulas: SURVEY.md Appendix A.
+ * SE/M12/M32/M52/PERIODIC/CONST replace gpflow.kernels.{SquaredExponential,
+ * Matern12,Matern32,Matern52,Periodic(SquaredExponential),Constant}.K;
+ * LIN/POLY/CAT/EMPTY replace waveome/kernels.py:19-32, :56-73, :95-117, :136-139. */
+enum {
+  WV_K_SE = 0,
+  WV_K_M12 = 1,
+  WV_K_M32 = 2,
+  WV_K_M52 = 3,
+  WV_K_PERIODIC = 4, /* params: variance, lengthscales, period */
+  WV_K_LIN = 5,      /* params: variance */
+  WV_K_POLY = 6,     /* params: variance, offset; integer degree */
+  WV_K_CONST = 7,    /* params: variance */
+  WV_K_CAT = 8,      /* params: variance; 1[rint(x_i) == rint(x_j)] on one column */
+  WV_K_EMPTY = 9     /* no params; identically zero */
+};
+
+/* Parameter transforms (gpflow.utilities.positive() = Softplus; Gaussian
+ * likelihood variance = Softplus + Shift(1e-6); Constant mean = identity). */
+enum { WV_T_IDENTITY = 0, WV_T_SOFTPLUS = 1, WV_T_SOFTPLUS_SHIFT = 2 };
+
+#define WV_MAX_DIMS 32
+#define WV_MAX_PARAMS 256
+
+typedef struct {
+  int32_t type;      /* WV_K_* */
+  uint32_t dim_mask; /* bit d set <=> column d of X is active (gpflow active_dims) */
+  int32_t param[3];  /* indices into wv_kernel_spec.params; -1 = unused */
+  int32_t degree;    /* WV_K_POLY only */
+} wv_factor;
+
+typedef struct {
+  double init;         /* constrained initial value (GPflow default 1.0; mean 0.0) */
+  double prior_scale;  /* Horseshoe scale = 1/penalization_factor
+                          (waveome/model_classes.py:857-859); <= 0: no prior */
+  int32_t transform;   /* WV_T_* */
+  int32_t trainable;   /* 0 = frozen (e.g. Categorical variance inside a Product,
+                          waveome/regularization.py:109,132) */
+} wv_param;
+
+/* K(x, x') = sum_t prod_{f in term t} k_f(x, x')   (gpflow Sum of Products,
+ * waveome/regularization.py:112,139,166,181).  The objective maximised is
+ *   LML(y | c, K + sigma^2 I) + sum_{trainable p with prior} log p_HS(theta_p)
+ * (waveome/model_classes.py:817-864). */
+typedef struct {
+  int32_t n_dims;   /* D */
+  int32_t n_params; /* <= WV_MAX_PARAMS */
+  const wv_param* params;
+  int32_t n_terms;
+  const int32_t* term_start; /* n_terms + 1 offsets into factors */
+  const wv_factor* factors;
+  int32_t noise_param; /* index of the likelihood variance */
+  int32_t mean_param;  /* index of the Constant mean c, or -1 (zero mean) */
+} wv_kernel_spec;
+
+/* SciPy L-BFGS-B options as gpflow.optimizers.Scipy passes them
+ * (waveome/model_classes.py:310-315, 325-334).  Zero-initialise then call
+ * wv_lbfgs_default_opts for SciPy's defaults with the reference's
+ * maxiter = maxfun = 50000. */
+typedef struct {
+  int32_t m;       /* maxcor, 10 */
+  int32_t maxiter; /* 50000 */
+  int32_t maxfun;  /* 50000 */
+  int32_t maxls;   /* 20 */
+  double ftol;     /* 2.220446049250313e-09 */
+  double gtol;     /* 1e-05 */
+} wv_lbfgs_opts;
+
+/* Fit termination codes (wv_fit status_out, wv_lbfgs_feed return value). */
+enum {
+  WV_LB_FG = 1,            /* evaluate f,g at wv_lbfgs_x() and feed again */
+  WV_LB_CONV_GTOL = 0,     /* CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL */
+  WV_LB_CONV_FTOL = 2,     /* CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH */
+  WV_LB_STOP_MAXITER = 3,  /* STOP: TOTAL NO. of ITERATIONS REACHED LIMIT */
+  WV_LB_STOP_MAXFUN = 4,   /* STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT */
+  WV_LB_ABNORMAL = 5       /* ABNORMAL_TERMINATION_IN_LNSRCH */
+};
+
+int32_t wv_abi_version(void);
+const char* wv_last_error(void);
+void wv_lbfgs_default_opts(wv_lbfgs_opts* opts);
+
+/* ---- host-only helpers (usable without a GPU) ------------------------- */
+
+/* Validate a spec; n_trainable_out receives the length of the unconstrained
+ * vector (trainable parameters in table order, the order
+ * gpflow `trainable_variables` would be flattened in is irrelevant to L-BFGS). */
+int32_t wv_spec_check(const wv_kernel_spec* spec, int32_t* n_trainable_out);
+/* unconstrained trainables -> constrained full table (frozen entries = init). */
+int32_t wv_spec_constrain(const wv_kernel_spec* spec, const double* u, double* theta_out);
+/* constrained full table -> unconstrained trainables. */
+int32_t wv_spec_unconstrain(const wv_kernel_spec* spec, const double* theta, double* u_out);
+/* sum of Horseshoe log-densities over trainable params with a prior, and its
+ * gradient w.r.t. the constrained values (grad_out may be NULL). Restates
+ * tfd.Horseshoe.log_prob, call site waveome/model_classes.py:857-864. */
+int32_t wv_spec_log_prior(const wv_kernel_spec* spec, const double* theta, double* value_out,
+                          double* grad_out);
+
+/* Reverse-communication L-BFGS-B (no bounds) - replaces
+ * gpflow.optimizers.Scipy().minimize(method="L-BFGS-B")
+ * (waveome/model_classes.py:325-334).  create -> x() -> feed(f,g) until the
+ * return value is not WV_LB_FG. */
+int32_t wv_lbfgs_create(int32_t n, const wv_lbfgs_opts* opts, const double* x0, wv_lbfgs** out);
+const double* wv_lbfgs_x(const wv_lbfgs* s);
+int32_t wv_lbfgs_feed(wv_lbfgs* s, double f, const double* g);
+int32_t wv_lbfgs_n_iter(const wv_lbfgs* s);
+int32_t wv_lbfgs_n_eval(const wv_lbfgs* s);
+double wv_lbfgs_f(const wv_lbfgs* s);
+void wv_lbfgs_destroy(wv_lbfgs* s);
+
+/* ---- device path ------------------------------------------------------ */
+
+int32_t wv_device_count(int32_t* count_out);
+/* One context per GPU / process.  dtype: 0 = float64 (only value supported in ABI v1). */
+int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out);
+void wv_ctx_destroy(wv_ctx* ctx);
+
+/* Copies X (N x D) and Y (P x N) to HBM once, uploads the spec and sizes the
+ * workspace for `max_batch` fits in flight (two N x N matrices per slot).
+ * Replaces PSVGP.__init__ data staging, waveome/model_classes.py:123-140.
+ * x_is_device / y_is_device != 0: the pointers are device pointers on this
+ * context's GPU (e.g. buffers an RCCL broadcast filled); they are copied D2D. */
+int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
+                          int32_t P, const wv_kernel_spec* spec, int32_t max_batch,
+                          int32_t x_is_device, int32_t y_is_device, wv_problem** out);
+void wv_problem_destroy(wv_problem* prob);
+int64_t wv_problem_workspace_bytes(const wv_problem* prob);
+
+/* Bring-up / parity: K_y = K_theta(X,X) + sigma^2 I for ONE constrained
+ * parameter table, copied back as a full symmetric N x N host matrix.
+ * Replaces kernel(X) + add_likelihood_noise_cov, waveome/model_types_DEPR.py:50-51. */
+int32_t wv_gram(wv_problem* prob, const double* theta, double* K_out);
+
+/* Exact LML at given constrained tables (no prior, no gradient) for B tasks.
+ * Replaces PGPR.log_marginal_likelihood(penalize=False),
+ * waveome/model_types_DEPR.py:49-56 (= gpflow GPR.log_marginal_likelihood). */
+int32_t wv_lml(wv_problem* prob, const int32_t* col_idx, int32_t B, const double* theta,
+               double* lml_out, int32_t* status_out);
+
+/* Training loss -(LML + log prior) and its gradient in UNCONSTRAINED
+ * coordinates for B tasks; theta_u is B x n_trainable.  Replaces the compiled
+ * `training_loss_closure` + tape.gradient the SciPy wrapper calls
+ * (waveome/model_classes.py:325-334).  status: 0 ok, 1 = Gram matrix not PD
+ * (loss = +inf, gradient zeros). B <= max_batch. */
+int32_t wv_value_grad(wv_problem* prob, const int32_t* col_idx, int32_t B, const double* theta_u,
+                      double* loss_out, double* grad_out, int32_t* status_out);
+
+/* Fit n_tasks independent (column, start point) tasks with L-BFGS-B, keeping up
+ * to max_batch of them in flight on the GPU.  theta_u_inout is n_tasks x
+ * n_trainable (start points in, optima out).  Replaces the per-output
+ * `mod.optimize_params(optimizer="scipy")` calls that
+ * GPSearch.penalized_optimization farms out through Ray
+ * (waveome/model_search.py:250-329, 474-489).  Any out pointer may be NULL. */
+int32_t wv_fit(wv_problem* prob, const int32_t* col_idx, int32_t n_tasks,
+               const wv_lbfgs_opts* opts, double* theta_u_inout, double* loss_out, double* lml_out,
+               int32_t* n_iter_out, int32_t* n_eval_out, int32_t* status_out);
+
+/* Posterior prediction at the optimum for ONE task: mean and variance of f (and
+ * of y = f + noise when include_noise != 0) at Xnew (M x D).  Replaces
+ * predict_f / predict_y (waveome/model_classes.py:526-544) for the exact GP. */
+int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const double* Xnew, int64_t M,
+                   int32_t include_noise, double* mean_out, double* var_out);
+
+/* Timing of the device stages of the most recent wv_value_grad / wv_fit on this
+ * problem, measured with HIP events on the stream the kernels ran on.
+ * names_out receives up to `cap` pointers to static strings; ms_out and
+ * launches_out the accumulated milliseconds / launch counts.  Returns the
+ * number of stages. */
+int32_t wv_stage_times(wv_problem* prob, int32_t cap, const char** names_out, double* ms_out,
+                       int64_t* launches_out, double* flops_out, double* bytes_out);
+void wv_stage_times_reset(wv_problem* prob);
+void wv_stage_timing_enable(wv_problem* prob, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEOME_AMD_H */

@@ -1,0 +1,610 @@
+// C-ABI device entry points (include/waveome_amd.h): contexts, problems, batched evaluation
+// and the batched L-BFGS-B fit driver.  Host logic only - the kernels live in wv_gram.hip,
+// wv_gemm.hip and wv_chol.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "wv_device.hpp"
+#include "wv_lbfgs.hpp"
+
+namespace wv {
+
+const char* const kStageNames[ST_COUNT] = {
+    "gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
+    "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce"};
+
+// ---------------- stage timer ----------------
+void StageTimer::begin(hipStream_t s, int stage) {
+  if (!enabled) return;
+  Rec r;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!pool.empty()) {
+      e = pool.back();
+      pool.pop_back();
+    } else {
+      hipEventCreate(&e);
+    }
+    return e;
+  };
+  r.a = get();
+  r.b = get();
+  r.stage = stage;
+  hipEventRecord(r.a, s);
+  pending.push_back(r);
+}
+void StageTimer::end(hipStream_t s) {
+  if (!enabled || pending.empty()) return;
+  hipEventRecord(pending.back().b, s);
+}
+void StageTimer::collect() {
+  for (auto& r : pending) {
+    hipEventSynchronize(r.b);
+    float t = 0;
+    hipEventElapsedTime(&t, r.a, r.b);
+    ms[r.stage] += t;
+    launches[r.stage] += 1;
+    pool.push_back(r.a);
+    pool.push_back(r.b);
+  }
+  pending.clear();
+}
+void StageTimer::reset() {
+  collect();
+  for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0, launches[i] = 0, flops[i] = 0, bytes[i] = 0;
+}
+StageTimer::~StageTimer() {
+  for (auto& r : pending) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  for (auto e : pool) hipEventDestroy(e);
+}
+
+// ---------------- device spec ----------------
+std::string build_devspec(const Spec& s, DevSpec& d) {
+  std::memset(&d, 0, sizeof(d));
+  if (s.n_terms() > 64) return "more than 64 additive terms";
+  if ((int)s.factors.size() > 128) return "more than 128 factors";
+  d.n_terms = s.n_terms();
+  d.n_factors = (int)s.factors.size();
+  d.n_params = s.n_params();
+  d.noise_param = s.noise_param;
+  d.mean_param = s.mean_param;
+  d.n_dims = s.n_dims;
+  for (int t = 0; t <= s.n_terms(); ++t) d.term_start[t] = s.term_start[t];
+  for (int t = 0; t < s.n_terms(); ++t)
+    if (s.term_start[t + 1] - s.term_start[t] > MAX_TERM_F) return "more than 4 factors in a product";
+  int nfeat = 0, nslot = 0;
+  auto feat = [&](int kind, int dim, int param) -> int {
+    for (int i = 0; i < nfeat; ++i)
+      if (d.feat[i].kind == kind && d.feat[i].dim == dim && d.feat[i].param == param) return i;
+    if (nfeat >= MAX_FEAT) return -1;
+    d.feat[nfeat] = FeatOp{kind, dim, param, 0};
+    return nfeat++;
+  };
+  for (size_t fi = 0; fi < s.factors.size(); ++fi) {
+    const wv_factor& f = s.factors[fi];
+    DevFactor& o = d.factors[fi];
+    o.type = f.type;
+    o.degree = f.degree;
+    o.slot0 = nslot;
+    o.ndims = 0;
+    int np = n_factor_params(f.type);
+    for (int k = 0; k < 3; ++k) {
+      o.p[k] = k < np ? f.param[k] : 0;
+      if (k < np && s.params[f.param[k]].trainable) o.trainable |= (1 << k);
+    }
+    if (f.type == WV_K_EMPTY || f.type == WV_K_CONST) continue;
+    for (int dim = 0; dim < s.n_dims; ++dim) {
+      if (!(f.dim_mask & (1u << dim))) continue;
+      int need = f.type == WV_K_PERIODIC ? 3 : 1;
+      if (nslot + need > 512) return "feature slot table overflow";
+      if (f.type == WV_K_PERIODIC) {
+        int a = feat(FEAT_SINPI, dim, f.param[2]), b = feat(FEAT_COSPI, dim, f.param[2]),
+            c = feat(FEAT_RAW, dim, -1);
+        if (a < 0 || b < 0 || c < 0) return "more than 64 staged features (too many periodic factors)";
+        d.fslots[nslot++] = (int16_t)a;
+        d.fslots[nslot++] = (int16_t)b;
+        d.fslots[nslot++] = (int16_t)c;
+      } else {
+        int a = feat(f.type == WV_K_CAT ? FEAT_RINT : FEAT_RAW, dim, -1);
+        if (a < 0) return "more than 64 staged features";
+        d.fslots[nslot++] = (int16_t)a;
+      }
+      o.ndims++;
+    }
+  }
+  d.n_feat = nfeat;
+  return "";
+}
+
+// ---------------- evaluation pipeline ----------------
+// Enqueue one batched evaluation for the first `nb` slots of group g; results land in the
+// group's pinned h_out / h_status when g.done fires.
+static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
+  hipStream_t st = g.stream;
+  const int np = p.spec.n_params();
+  WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np, g.h_theta, sizeof(double) * np * nb,
+                            hipMemcpyHostToDevice, st));
+  WV_HIP_TRY(hipMemcpyAsync(p.dcol + g.slot0, g.h_col, sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
+  launch_resid(p, st, g.slot0, nb);
+  launch_gram(p, st, g.slot0, nb, 0);
+  cholesky(p, st, g.slot0, nb);
+  trtri(p, st, g.slot0, nb);
+  launch_solve(p, st, g.slot0, nb, with_grad);
+  if (with_grad) {
+    lauum(p, st, g.slot0, nb);
+    launch_trace(p, st, g.slot0, nb);
+  }
+  launch_reduce(p, st, g.slot0, nb, with_grad);
+  WV_HIP_TRY(hipMemcpyAsync(g.h_out, p.dout + (int64_t)g.slot0 * p.out_stride,
+                            sizeof(double) * p.out_stride * nb, hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipMemcpyAsync(g.h_status, p.dstatus + g.slot0, sizeof(int32_t) * nb,
+                            hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipEventRecord(g.done, st));
+  WV_HIP_TRY(hipGetLastError());
+  return WV_OK;
+}
+
+static int wait_group(Problem& p, Group& g) {
+  WV_HIP_TRY(hipEventSynchronize(g.done));
+  if (p.timer.enabled) p.timer.collect();
+  return WV_OK;
+}
+
+// loss = -(LML + log prior), gradient w.r.t. unconstrained trainables, from a result record
+static void loss_from_record(const Problem& p, const double* u, const double* theta, const double* rec,
+                             int status, double* loss, double* grad_u, double* lml_out) {
+  const Spec& s = p.spec;
+  const int nt = s.n_trainable();
+  double lml = rec[0];
+  bool ok = status == 0 && std::isfinite(lml);
+  if (lml_out) *lml_out = ok ? lml : -std::numeric_limits<double>::infinity();
+  if (!ok) {
+    *loss = std::numeric_limits<double>::infinity();
+    if (grad_u) std::fill(grad_u, grad_u + nt, 0.0);
+    return;
+  }
+  std::vector<double> gp(s.n_params());
+  double lp = s.log_prior(theta, grad_u ? gp.data() : nullptr);
+  *loss = -(lml + lp);
+  if (grad_u) {
+    for (int k = 0; k < nt; ++k) {
+      int i = s.trainable[k];
+      grad_u[k] = -(rec[3 + i] + gp[i]) * s.dconstrain(k, u[k]);
+    }
+  }
+}
+
+}  // namespace wv
+
+using namespace wv;
+
+struct wv_ctx {
+  Ctx c;
+};
+struct wv_problem {
+  Problem p;
+};
+
+extern "C" {
+
+int32_t wv_device_count(int32_t* count_out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    n = 0;
+    (void)hipGetLastError();
+  }
+  if (count_out) *count_out = n;
+  return WV_OK;
+}
+
+int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out) {
+  if (!out) {
+    set_error("wv_ctx_create: out is NULL");
+    return WV_E_BADARG;
+  }
+  if (dtype != 0) {
+    set_error("wv_ctx_create: only dtype 0 (float64) is implemented in ABI v1");
+    return WV_E_UNSUPPORTED;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible (this library has no CPU fallback)");
+    return WV_E_NODEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) {
+    set_error("device ordinal out of range");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(device_ordinal));
+  auto* c = new wv_ctx();
+  c->c.device = device_ordinal;
+  if (hipGetDeviceProperties(&c->c.prop, device_ordinal) != hipSuccess) {
+    delete c;
+    set_error("hipGetDeviceProperties failed");
+    return WV_E_HIP;
+  }
+  if (std::string(c->c.prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    std::string arch = c->c.prop.gcnArchName;
+    delete c;
+    set_error("device is " + arch + ", this library is built for gfx950 only");
+    return WV_E_NODEVICE;
+  }
+  *out = c;
+  return WV_OK;
+}
+
+void wv_ctx_destroy(wv_ctx* ctx) { delete ctx; }
+
+void wv_problem_destroy(wv_problem* h) {
+  if (!h) return;
+  Problem& p = h->p;
+  if (p.ctx) (void)hipSetDevice(p.ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& g : p.groups) {
+    if (g.stream) hipStreamDestroy(g.stream);
+    if (g.done) hipEventDestroy(g.done);
+    if (g.h_theta) hipHostFree(g.h_theta);
+    if (g.h_col) hipHostFree(g.h_col);
+    if (g.h_out) hipHostFree(g.h_out);
+    if (g.h_status) hipHostFree(g.h_status);
+  }
+  void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus};
+  for (void* q : ptrs)
+    if (q) hipFree(q);
+  delete h;
+}
+
+int64_t wv_problem_workspace_bytes(const wv_problem* h) { return h ? h->p.workspace_bytes : 0; }
+
+int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
+                          int32_t P, const wv_kernel_spec* spec, int32_t max_batch,
+                          int32_t x_is_device, int32_t y_is_device, wv_problem** out) {
+  if (!ctx || !X || !Y || !spec || !out || N < 1 || D < 1 || P < 1 || max_batch < 1) {
+    set_error("wv_problem_create: bad argument");
+    return WV_E_BADARG;
+  }
+  if (N > (1 << 20)) {
+    set_error("N too large");
+    return WV_E_BADARG;
+  }
+  std::unique_ptr<wv_problem, void (*)(wv_problem*)> h(new wv_problem(), wv_problem_destroy);
+  Problem& p = h->p;
+  p.ctx = &ctx->c;
+  std::string e = Spec::parse(spec, p.spec);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (p.spec.n_dims != D) {
+    set_error("spec.n_dims != D");
+    return WV_E_SPEC;
+  }
+  e = build_devspec(p.spec, p.hspec);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_UNSUPPORTED;
+  }
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  p.N = N;
+  p.Npad = (N + NB - 1) / NB * NB;
+  p.D = D;
+  p.P = P;
+  p.max_batch = max_batch;
+  p.out_stride = out_stride_for(p.spec.n_params());
+  const int64_t Np = p.Npad, mat = Np * Np;
+  const int np = p.spec.n_params();
+  int64_t total = 0;
+  auto alloc = [&](void** ptr, int64_t bytes) -> bool {
+    if (hipMalloc(ptr, (size_t)bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    total += bytes;
+    return true;
+  };
+  bool ok = alloc((void**)&p.dX, sizeof(double) * Np * D) && alloc((void**)&p.dY, sizeof(double) * Np * P) &&
+            alloc((void**)&p.dspec, sizeof(DevSpec)) &&
+            alloc((void**)&p.Kbuf, sizeof(double) * mat * max_batch) &&
+            alloc((void**)&p.Mbuf, sizeof(double) * mat * max_batch) &&
+            alloc((void**)&p.Pbuf, sizeof(double) * Np * NB * max_batch) &&
+            alloc((void**)&p.dtheta, sizeof(double) * np * max_batch) &&
+            alloc((void**)&p.dr, sizeof(double) * Np * max_batch) &&
+            alloc((void**)&p.dz, sizeof(double) * Np * max_batch) &&
+            alloc((void**)&p.dalpha, sizeof(double) * Np * max_batch) &&
+            alloc((void**)&p.dlogdet, sizeof(double) * p.nblk() * max_batch) &&
+            alloc((void**)&p.dpart, sizeof(double) * trace_nwg(p) * np * max_batch) &&
+            alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&
+            alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
+            alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
+  if (!ok) {
+    set_error("device allocation failed (workspace for max_batch fits does not fit in HBM)");
+    return WV_E_OOM;
+  }
+  p.workspace_bytes = total;
+  const int nwg = trace_nwg(p);
+  WV_HIP_TRY(hipMemset(p.dX, 0, sizeof(double) * Np * D));
+  WV_HIP_TRY(hipMemset(p.dY, 0, sizeof(double) * Np * P));
+  WV_HIP_TRY(hipMemset(p.Kbuf, 0, sizeof(double) * mat * max_batch));
+  WV_HIP_TRY(hipMemset(p.Mbuf, 0, sizeof(double) * mat * max_batch));
+  WV_HIP_TRY(hipMemset(p.dalpha, 0, sizeof(double) * Np * max_batch));
+  WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * np * max_batch));
+  WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, Y, sizeof(double) * N, sizeof(double) * N, P,
+                         y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(p.dspec, &p.hspec, sizeof(DevSpec), hipMemcpyHostToDevice));
+  // batch groups: independent streams so one group's small serial kernels (diagonal blocks,
+  // panels) overlap another group's large GEMMs and the host's L-BFGS work.
+  int ng = 2;
+  if (const char* s = std::getenv("WV_GROUPS")) ng = std::max(1, std::atoi(s));
+  ng = std::min(ng, max_batch);
+  int base = max_batch / ng, extra = max_batch % ng, at = 0;
+  p.groups.resize(ng);
+  for (int i = 0; i < ng; ++i) {
+    Group& g = p.groups[i];
+    g.slot0 = at;
+    g.nslots = base + (i < extra ? 1 : 0);
+    at += g.nslots;
+    WV_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    WV_HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    WV_HIP_TRY(hipHostMalloc((void**)&g.h_theta, sizeof(double) * np * g.nslots));
+    WV_HIP_TRY(hipHostMalloc((void**)&g.h_col, sizeof(int32_t) * g.nslots));
+    WV_HIP_TRY(hipHostMalloc((void**)&g.h_out, sizeof(double) * p.out_stride * g.nslots));
+    WV_HIP_TRY(hipHostMalloc((void**)&g.h_status, sizeof(int32_t) * g.nslots));
+  }
+  *out = h.release();
+  return WV_OK;
+}
+
+static int check_cols(const Problem& p, const int32_t* col_idx, int n) {
+  for (int i = 0; i < n; ++i)
+    if (col_idx[i] < 0 || col_idx[i] >= p.P) {
+      set_error("column index out of range");
+      return WV_E_BADARG;
+    }
+  return WV_OK;
+}
+
+int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
+  if (!h || !theta || !K_out) {
+    set_error("wv_gram: null argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  Group& g = p.groups[0];
+  const int np = p.spec.n_params();
+  std::memcpy(g.h_theta, theta, sizeof(double) * np);
+  WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np, g.h_theta, sizeof(double) * np,
+                            hipMemcpyHostToDevice, g.stream));
+  launch_gram(p, g.stream, g.slot0, 1, 1);
+  WV_HIP_TRY(hipGetLastError());
+  WV_HIP_TRY(hipMemcpy2DAsync(K_out, sizeof(double) * p.N, p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad,
+                              sizeof(double) * p.Npad, sizeof(double) * p.N, p.N,
+                              hipMemcpyDeviceToHost, g.stream));
+  WV_HIP_TRY(hipStreamSynchronize(g.stream));
+  // the upper triangle of Kbuf must be zero again for the factorisation path
+  WV_HIP_TRY(hipMemsetAsync(p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad, 0, sizeof(double) * p.Npad * p.Npad, g.stream));
+  WV_HIP_TRY(hipStreamSynchronize(g.stream));
+  return WV_OK;
+}
+
+// shared by wv_lml / wv_value_grad: evaluate B tasks given constrained tables
+static int eval_batch(Problem& p, const int32_t* col_idx, int B, const double* theta_rows, bool with_grad,
+                      std::vector<double>& recs, std::vector<int32_t>& status) {
+  const int np = p.spec.n_params();
+  recs.resize((size_t)B * p.out_stride);
+  status.resize(B);
+  int done = 0;
+  // round-robin chunks over the groups
+  struct Inflight { int g; int first; int n; };
+  std::vector<Inflight> fl;
+  size_t gi = 0;
+  while (done < B || !fl.empty()) {
+    while (done < B && fl.size() < p.groups.size()) {
+      Group& g = p.groups[gi % p.groups.size()];
+      int n = std::min(g.nslots, B - done);
+      std::memcpy(g.h_theta, theta_rows + (size_t)done * np, sizeof(double) * np * n);
+      std::memcpy(g.h_col, col_idx + done, sizeof(int32_t) * n);
+      int rc = enqueue_eval(p, g, n, with_grad);
+      if (rc != WV_OK) return rc;
+      fl.push_back({(int)(gi % p.groups.size()), done, n});
+      done += n;
+      ++gi;
+    }
+    Inflight f = fl.front();
+    fl.erase(fl.begin());
+    Group& g = p.groups[f.g];
+    int rc = wait_group(p, g);
+    if (rc != WV_OK) return rc;
+    std::memcpy(&recs[(size_t)f.first * p.out_stride], g.h_out, sizeof(double) * p.out_stride * f.n);
+    std::memcpy(&status[f.first], g.h_status, sizeof(int32_t) * f.n);
+  }
+  return WV_OK;
+}
+
+int32_t wv_lml(wv_problem* h, const int32_t* col_idx, int32_t B, const double* theta, double* lml_out,
+               int32_t* status_out) {
+  if (!h || !col_idx || !theta || !lml_out || B < 1) {
+    set_error("wv_lml: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = check_cols(p, col_idx, B);
+  if (rc != WV_OK) return rc;
+  std::vector<double> recs;
+  std::vector<int32_t> st;
+  rc = eval_batch(p, col_idx, B, theta, false, recs, st);
+  if (rc != WV_OK) return rc;
+  for (int i = 0; i < B; ++i) {
+    double v = recs[(size_t)i * p.out_stride];
+    bool ok = st[i] == 0 && std::isfinite(v);
+    lml_out[i] = ok ? v : -std::numeric_limits<double>::infinity();
+    if (status_out) status_out[i] = ok ? 0 : 1;
+  }
+  return WV_OK;
+}
+
+int32_t wv_value_grad(wv_problem* h, const int32_t* col_idx, int32_t B, const double* theta_u,
+                      double* loss_out, double* grad_out, int32_t* status_out) {
+  if (!h || !col_idx || !theta_u || !loss_out || B < 1) {
+    set_error("wv_value_grad: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = check_cols(p, col_idx, B);
+  if (rc != WV_OK) return rc;
+  const int np = p.spec.n_params(), nt = p.spec.n_trainable();
+  std::vector<double> theta((size_t)B * np);
+  for (int i = 0; i < B; ++i) p.spec.constrain(theta_u + (size_t)i * nt, &theta[(size_t)i * np]);
+  std::vector<double> recs;
+  std::vector<int32_t> st;
+  rc = eval_batch(p, col_idx, B, theta.data(), true, recs, st);
+  if (rc != WV_OK) return rc;
+  for (int i = 0; i < B; ++i) {
+    loss_from_record(p, theta_u + (size_t)i * nt, &theta[(size_t)i * np], &recs[(size_t)i * p.out_stride],
+                     st[i], &loss_out[i], grad_out ? grad_out + (size_t)i * nt : nullptr, nullptr);
+    if (status_out) status_out[i] = std::isfinite(loss_out[i]) ? 0 : 1;
+  }
+  return WV_OK;
+}
+
+int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_lbfgs_opts* opts,
+               double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
+               int32_t* n_eval_out, int32_t* status_out) {
+  if (!h || !col_idx || !opts || !theta_u_inout || n_tasks < 1) {
+    set_error("wv_fit: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = check_cols(p, col_idx, n_tasks);
+  if (rc != WV_OK) return rc;
+  const int np = p.spec.n_params(), nt = p.spec.n_trainable();
+  if (nt < 1) {
+    set_error("wv_fit: no trainable parameters");
+    return WV_E_SPEC;
+  }
+  struct Slot {
+    int task = -1;
+    std::unique_ptr<Lbfgs> opt;
+    double last_lml = 0;
+  };
+  const int ng = (int)p.groups.size();
+  std::vector<std::vector<Slot>> slots(ng);
+  std::vector<int> inflight(ng, 0);  // number of slots evaluated by the pending launch
+  int next_task = 0, finished = 0;
+  std::vector<double> gu(nt), theta(np);
+
+  auto refill_and_launch = [&](int gi) -> int {
+    Group& g = p.groups[gi];
+    auto& sl = slots[gi];
+    // drop finished slots, pull new tasks, keep active tasks packed at the front
+    std::vector<Slot> act;
+    for (auto& s : sl)
+      if (s.task >= 0) act.push_back(std::move(s));
+    while ((int)act.size() < g.nslots && next_task < n_tasks) {
+      Slot s;
+      s.task = next_task++;
+      s.opt.reset(new Lbfgs(nt, *opts, theta_u_inout + (size_t)s.task * nt));
+      act.push_back(std::move(s));
+    }
+    sl = std::move(act);
+    inflight[gi] = (int)sl.size();
+    if (sl.empty()) return WV_OK;
+    for (size_t i = 0; i < sl.size(); ++i) {
+      p.spec.constrain(sl[i].opt->x(), g.h_theta + i * np);
+      g.h_col[i] = col_idx[sl[i].task];
+    }
+    return enqueue_eval(p, g, (int)sl.size(), true);
+  };
+
+  for (int gi = 0; gi < ng; ++gi) {
+    rc = refill_and_launch(gi);
+    if (rc != WV_OK) return rc;
+  }
+  int gi = 0;
+  while (finished < n_tasks) {
+    if (inflight[gi] == 0) {
+      gi = (gi + 1) % ng;
+      continue;
+    }
+    Group& g = p.groups[gi];
+    rc = wait_group(p, g);
+    if (rc != WV_OK) return rc;
+    auto& sl = slots[gi];
+    for (size_t i = 0; i < sl.size(); ++i) {
+      Slot& s = sl[i];
+      double loss, lml;
+      // h_theta still holds the constrained table this evaluation used
+      loss_from_record(p, s.opt->x(), g.h_theta + i * np, g.h_out + i * p.out_stride, g.h_status[i], &loss,
+                       gu.data(), &lml);
+      int task = s.opt->feed(loss, gu.data());
+      if (std::isfinite(loss)) s.last_lml = lml;
+      if (task != WV_LB_FG) {
+        const int t = s.task;
+        std::memcpy(theta_u_inout + (size_t)t * nt, s.opt->x(), sizeof(double) * nt);
+        if (loss_out) loss_out[t] = s.opt->f();
+        if (n_iter_out) n_iter_out[t] = s.opt->n_iter();
+        if (n_eval_out) n_eval_out[t] = s.opt->n_eval();
+        if (status_out) status_out[t] = task;
+        if (lml_out) {
+          // LML at the returned point = -(loss) - log prior
+          p.spec.constrain(s.opt->x(), theta.data());
+          lml_out[t] = -s.opt->f() - p.spec.log_prior(theta.data(), nullptr);
+        }
+        s.task = -1;
+        ++finished;
+      }
+    }
+    rc = refill_and_launch(gi);
+    if (rc != WV_OK) return rc;
+    gi = (gi + 1) % ng;
+  }
+  return WV_OK;
+}
+
+int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double* Xnew, int64_t M,
+                   int32_t include_noise, double* mean_out, double* var_out) {
+  (void)h; (void)col; (void)theta; (void)Xnew; (void)M; (void)include_noise; (void)mean_out; (void)var_out;
+  set_error("wv_predict: not implemented in this build");
+  return WV_E_UNSUPPORTED;
+}
+
+int32_t wv_stage_times(wv_problem* h, int32_t cap, const char** names_out, double* ms_out,
+                       int64_t* launches_out, double* flops_out, double* bytes_out) {
+  if (!h) return 0;
+  Problem& p = h->p;
+  p.timer.collect();
+  int n = std::min<int>(cap, ST_COUNT);
+  for (int i = 0; i < n; ++i) {
+    if (names_out) names_out[i] = kStageNames[i];
+    if (ms_out) ms_out[i] = p.timer.ms[i];
+    if (launches_out) launches_out[i] = p.timer.launches[i];
+    if (flops_out) flops_out[i] = p.timer.flops[i];
+    if (bytes_out) bytes_out[i] = p.timer.bytes[i];
+  }
+  return ST_COUNT;
+}
+void wv_stage_times_reset(wv_problem* h) {
+  if (h) h->p.timer.reset();
+}
+void wv_stage_timing_enable(wv_problem* h, int32_t on) {
+  if (h) {
+    h->p.timer.collect();
+    h->p.timer.enabled = on != 0;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// Blocked factorisation / inversion schedules and the small kernels around the MFMA GEMMs.
+//
+// Per evaluation and batch slot (reference: tf.linalg.cholesky + triangular_solve forward and
+// reverse mode under gpflow's log marginal likelihood, waveome/model_types_DEPR.py:49-56):
+//   cholesky: K_y = L L'    right-looking, two-level blocking (outer 256, inner 64):
+//             potrf_diag (64x64 in LDS, also writes inv(L_jj) and log-det partials)
+//             -> TRSM as GEMM with inv(L_jj) -> panel update (K = 64) -> trailing SYRK (K = 256)
+//   trtri:    M = L^-1      by block columns right to left:  P = M22 L21,  M21 = -P M_jj
+//   lauum:    K_y^-1 = M' M one launch, lower tiles, contraction over rows >= tile row
+//   solve:    z = M r, alpha = M' z (HBM-bound matvecs), reduce: LML and gradient assembly.
+#include "wv_device.hpp"
+
+namespace wv {
+
+constexpr int OUTER = 256;  // outer Cholesky block
+constexpr int DS = NB + 1;  // LDS row stride of the 64x64 diagonal block
+
+// ---------------------------------------------------------------------------------------
+// potrf_diag: factor the 64x64 diagonal block at (j0, j0) of every slot's Kbuf in LDS, write
+// L_jj back (upper part zeroed), inv(L_jj) into Mbuf's diagonal block, sum log L_ii.
+// A non-positive / NaN pivot sets status[slot] = 1 and is replaced by 1 so the pipeline
+// keeps running on finite numbers (the host reports +inf for that task).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Kall,
+                                                         double* __restrict__ Mall,
+                                                         double* __restrict__ logdet,
+                                                         int32_t* __restrict__ status,
+                                                         int64_t Npad, int nblk, int slot0, int j0) {
+  __shared__ double L[NB * DS];
+  __shared__ double X[NB * DS];
+  __shared__ double T[NB * DS];
+  __shared__ int bad;
+  const int b = slot0 + blockIdx.x;
+  double* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  double* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int q = tid; q < NB * NB; q += 256) {
+    int i = q >> 6, j = q & 63;
+    L[i * DS + j] = (j <= i) ? K[(int64_t)i * Npad + j] : 0.0;
+    X[i * DS + j] = 0.0;
+  }
+  __syncthreads();
+  // unblocked right-looking Cholesky, two barriers per column
+  for (int j = 0; j < NB; ++j) {
+    double piv = L[j * DS + j];
+    bool ok = piv > 0.0;  // false for NaN too
+    if (!ok) piv = 1.0;
+    const double root = sqrt(piv), inv = 1.0 / root;
+    if (tid == 0 && !ok) bad = 1;
+    if (tid > j && tid < NB) L[tid * DS + j] *= inv;  // L[j][j] itself is rewritten below
+    __syncthreads();
+    // trailing update: (i, k) with j < k <= i < 64 (reads column j below the diagonal only)
+    const int rem = NB - 1 - j;
+    for (int q = tid; q < rem * rem; q += 256) {
+      int i = j + 1 + q / rem, k = j + 1 + q % rem;
+      if (k <= i) L[i * DS + k] -= L[i * DS + j] * L[k * DS + j];
+    }
+    if (tid == 255) L[j * DS + j] = root;
+    __syncthreads();
+  }
+  // write L back, accumulate the log-determinant partial
+  for (int q = tid; q < NB * NB; q += 256) {
+    int i = q >> 6, j = q & 63;
+    K[(int64_t)i * Npad + j] = L[i * DS + j];
+  }
+  if (tid < 64) {
+    double v = log(L[tid * DS + tid]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (tid == 0) {
+      logdet[(int64_t)b * nblk + j0 / NB] = v;
+      if (bad) status[b] = 1;
+    }
+  }
+  // ---- inverse of the lower-triangular block by recursive doubling ----
+  // level 0: four 16x16 diagonal blocks, one thread per column
+  if (tid < 64) {
+    const int blk = tid >> 4, c = tid & 15, o = blk * 16;
+    X[(o + c) * DS + o + c] = 1.0 / L[(o + c) * DS + o + c];
+    for (int i = c + 1; i < 16; ++i) {
+      double s = 0.0;
+      for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
+      X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
+    }
+  }
+  __syncthreads();
+  // level 1 (h = 16) and level 2 (h = 32): X21 = -X22 (L21 X11)
+  for (int h = 16; h <= 32; h <<= 1) {
+    const int nb2 = NB / (2 * h);  // number of 2h blocks
+    const int per = h * h;         // outputs per block
+    for (int q = tid; q < nb2 * per; q += 256) {
+      int blk = q / per, e = q % per, i = e / h, c = e % h, o = blk * 2 * h;
+      double s = 0.0;
+      for (int k = 0; k < h; ++k) s += L[(o + h + i) * DS + o + k] * X[(o + k) * DS + o + c];
+      T[(o + h + i) * DS + o + c] = s;
+    }
+    __syncthreads();
+    for (int q = tid; q < nb2 * per; q += 256) {
+      int blk = q / per, e = q % per, i = e / h, c = e % h, o = blk * 2 * h;
+      double s = 0.0;
+      for (int k = 0; k <= i; ++k) s += X[(o + h + i) * DS + o + h + k] * T[(o + h + k) * DS + o + c];
+      X[(o + h + i) * DS + o + c] = -s;
+    }
+    __syncthreads();
+  }
+  for (int q = tid; q < NB * NB; q += 256) {
+    int i = q >> 6, j = q & 63;
+    M[(int64_t)i * Npad + j] = X[i * DS + j];
+  }
+}
+
+void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
+  p.timer.begin(st, ST_POTRF_DIAG);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.dlogdet,
+                     p.dstatus, p.Npad, p.nblk(), slot0, j0);
+  p.timer.end(st);
+}
+
+// ---------------------------------------------------------------------------------------
+// residual r = y[col] - c (zero on padded rows); also clears the slot's status word
+// ---------------------------------------------------------------------------------------
+__global__ void resid_kernel(const DevSpec* __restrict__ sp, const double* __restrict__ Y,
+                             const int32_t* __restrict__ col, const double* __restrict__ theta,
+                             double* __restrict__ r, int32_t* __restrict__ status, int64_t N,
+                             int64_t Npad, int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  const double c = sp->mean_param >= 0 ? theta[(int64_t)b * sp->n_params + sp->mean_param] : 0.0;
+  r[(int64_t)b * Npad + i] = (i < N) ? Y[(int64_t)col[b] * Npad + i] - c : 0.0;
+  if (i == 0) status[b] = 0;
+}
+
+void launch_resid(Problem& p, hipStream_t st, int slot0, int nb) {
+  dim3 grid((unsigned)((p.Npad + 255) / 256), nb);
+  hipLaunchKernelGGL(resid_kernel, grid, dim3(256), 0, st, p.dspec, p.dY, p.dcol, p.dtheta, p.dr,
+                     p.dstatus, p.N, p.Npad, slot0);
+}
+
+// z = M r  (M lower triangular). One wave per row, 4 rows per wave, 16 rows per workgroup.
+__global__ __launch_bounds__(256) void trmv_kernel(const double* __restrict__ Mall,
+                                                   const double* __restrict__ rall,
+                                                   double* __restrict__ zall, int64_t Npad,
+                                                   int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const double* r = rall + (int64_t)b * Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t i = (int64_t)blockIdx.x * 16 + wave * 4 + rr;
+    const double* row = M + i * Npad;
+    double s = 0.0;
+    const int64_t len = i + 1;  // columns 0..i
+    for (int64_t j = 2 * lane; j < len; j += 128) {
+      double2 m = *reinterpret_cast<const double2*>(row + j);
+      double2 v = *reinterpret_cast<const double2*>(r + j);
+      s += m.x * v.x;
+      if (j + 1 < len) s += m.y * v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) zall[(int64_t)b * Npad + i] = s;
+  }
+}
+
+// alpha = M' z. Workgroup = 64 columns; wave w takes rows j0 + w, j0 + w + 4, ...
+__global__ __launch_bounds__(256) void trmv_t_kernel(const double* __restrict__ Mall,
+                                                     const double* __restrict__ zall,
+                                                     double* __restrict__ aall, int64_t Npad,
+                                                     int slot0) {
+  __shared__ double red[4][64];
+  const int b = slot0 + blockIdx.y;
+  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const double* z = zall + (int64_t)b * Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j0 = (int64_t)blockIdx.x * 64;
+  double s = 0.0;
+#pragma unroll 4
+  for (int64_t i = j0 + wave; i < Npad; i += 4) s += M[i * Npad + j0 + lane] * z[i];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) aall[(int64_t)b * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha) {
+  p.timer.begin(st, ST_SOLVE);
+  hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
+                     p.dz, p.Npad, slot0);
+  if (need_alpha)
+    hipLaunchKernelGGL(trmv_t_kernel, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, p.Mbuf,
+                       p.dz, p.dalpha, p.Npad, slot0);
+  p.timer.end(st);
+  p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * (double)p.Npad * (p.Npad + 1) / 2.0 * (need_alpha ? 2 : 1));
+}
+
+// ---------------------------------------------------------------------------------------
+// reduce: out[b] = {lml, quad, logdet, dLML/dtheta[0..np)}
+// ---------------------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__ sp,
+                                                     const double* __restrict__ zall,
+                                                     const double* __restrict__ aall,
+                                                     const double* __restrict__ logdet,
+                                                     const double* __restrict__ part,
+                                                     double* __restrict__ out, int64_t N,
+                                                     int64_t Npad, int nblk, int nwg,
+                                                     int out_stride, int slot0, int with_grad) {
+  __shared__ double sh[4];
+  const int b = slot0 + blockIdx.x, tid = threadIdx.x, np = sp->n_params;
+  double q = 0.0, sa = 0.0, ld = 0.0;
+  for (int64_t i = tid; i < Npad; i += 256) {
+    double zz = zall[(int64_t)b * Npad + i];
+    q += zz * zz;
+    if (with_grad) sa += aall[(int64_t)b * Npad + i];
+  }
+  for (int i = tid; i < nblk; i += 256) ld += logdet[(int64_t)b * nblk + i];
+  q = block_sum(q, sh);
+  ld = block_sum(ld, sh);
+  sa = block_sum(sa, sh);
+  double* o = out + (int64_t)b * out_stride;
+  if (tid == 0) {
+    o[0] = -0.5 * q - ld - 0.5 * (double)N * 1.8378770664093453;  // log(2 pi)
+    o[1] = q;
+    o[2] = ld;
+  }
+  if (with_grad) {
+    for (int p = tid; p < np; p += 256) {
+      double g = 0.0;
+      for (int w = 0; w < nwg; ++w) g += part[((int64_t)b * nwg + w) * np + p];
+      if (p == sp->mean_param) g = sa;
+      o[3 + p] = g;
+    }
+  }
+}
+
+void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad) {
+  p.timer.begin(st, ST_REDUCE);
+  hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dz, p.dalpha, p.dlogdet,
+                     p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p), p.out_stride, slot0,
+                     with_grad ? 1 : 0);
+  p.timer.end(st);
+}
+
+// ---------------------------------------------------------------------------------------
+// schedules
+// ---------------------------------------------------------------------------------------
+static GemmArgs base_args(const Problem& p, int slot0, int nb) {
+  GemmArgs a{};
+  const int64_t mat = p.Npad * p.Npad;
+  a.sA = a.sB = a.sC = mat;
+  a.lda = a.ldb = a.ldc = (int)p.Npad;
+  a.alpha = 1.0;
+  a.beta = 0.0;
+  a.nbatch = nb;
+  (void)slot0;
+  return a;
+}
+
+void cholesky(Problem& p, hipStream_t st, int slot0, int nb) {
+  const int64_t Np = p.Npad, mat = Np * Np;
+  double* K0 = p.Kbuf + (int64_t)slot0 * mat;
+  double* M0 = p.Mbuf + (int64_t)slot0 * mat;
+  for (int64_t o0 = 0; o0 < Np; o0 += OUTER) {
+    const int64_t W = std::min<int64_t>(OUTER, Np - o0);
+    for (int64_t j0 = o0; j0 < o0 + W; j0 += NB) {
+      launch_potrf_diag(p, st, slot0, nb, (int)j0);
+      const int64_t r0 = j0 + NB, rem = Np - r0;
+      if (rem <= 0) continue;
+      {  // TRSM: L21 = A21 * inv(L_jj)'  (NT, K = 64), in place
+        GemmArgs a = base_args(p, slot0, nb);
+        a.A = K0 + r0 * Np + j0;
+        a.B = M0 + j0 * Np + j0;  // inv(L_jj), row-major lower
+        a.C = K0 + r0 * Np + j0;
+        a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = NB;
+        p.timer.begin(st, ST_CHOL_TRSM);
+        launch_gemm(st, a, true, true, 64);
+        p.timer.end(st);
+        p.timer.work(ST_CHOL_TRSM, 2.0 * nb * (double)rem * NB * NB, 0.0);
+      }
+      const int64_t wrem = o0 + W - r0;  // panel columns still to update
+      if (wrem > 0) {  // A[r0:, r0:o0+W] -= L[r0:, j0:j0+64] L[r0:o0+W, j0:j0+64]'
+        GemmArgs a = base_args(p, slot0, nb);
+        a.A = K0 + r0 * Np + j0;
+        a.B = K0 + r0 * Np + j0;
+        a.C = K0 + r0 * Np + r0;
+        a.M = (int)rem; a.N = (int)wrem; a.kb = 0; a.ke = NB;
+        a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.tri_off = 0;
+        p.timer.begin(st, ST_CHOL_PANEL);
+        launch_gemm(st, a, true, true, wrem > 64 ? 128 : 64);
+        p.timer.end(st);
+        p.timer.work(ST_CHOL_PANEL, 2.0 * nb * NB * ((double)rem * wrem - 0.5 * (double)wrem * wrem), 0.0);
+      }
+    }
+    const int64_t t0 = o0 + W, rem = Np - t0;
+    if (rem > 0) {  // trailing SYRK: A[t0:, t0:] -= L[t0:, o0:t0] L[t0:, o0:t0]'
+      GemmArgs a = base_args(p, slot0, nb);
+      a.A = K0 + t0 * Np + o0;
+      a.B = K0 + t0 * Np + o0;
+      a.C = K0 + t0 * Np + t0;
+      a.M = (int)rem; a.N = (int)rem; a.kb = 0; a.ke = (int)W;
+      a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.tri_off = 0;
+      p.timer.begin(st, ST_CHOL_TRAIL);
+      launch_gemm(st, a, true, true, rem > 64 ? 128 : 64);
+      p.timer.end(st);
+      p.timer.work(ST_CHOL_TRAIL, nb * (double)W * (double)rem * (rem + 1), 0.0);
+    }
+  }
+}
+
+void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
+  const int64_t Np = p.Npad, mat = Np * Np;
+  double* K0 = p.Kbuf + (int64_t)slot0 * mat;
+  double* M0 = p.Mbuf + (int64_t)slot0 * mat;
+  double* P0 = p.Pbuf + (int64_t)slot0 * Np * NB;
+  for (int64_t j0 = Np - 2 * NB; j0 >= 0; j0 -= NB) {
+    const int64_t r0 = j0 + NB, rem = Np - r0;
+    {  // P = M22 * L21   (NN; M22 lower triangular -> K range ends at the tile's last row)
+      GemmArgs a = base_args(p, slot0, nb);
+      a.A = M0 + r0 * Np + r0;
+      a.B = K0 + r0 * Np + j0;  // L21 stored [k][n]
+      a.C = P0;
+      a.sC = Np * NB; a.ldc = NB;
+      a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = (int)rem; a.kmode = 1; a.koff = 0;
+      p.timer.begin(st, ST_TRTRI_A);
+      launch_gemm(st, a, true, false, 64);
+      p.timer.end(st);
+      p.timer.work(ST_TRTRI_A, nb * (double)NB * (double)rem * (rem + 1), 0.0);
+    }
+    {  // M21 = -P * M_jj   (NN, K = 64)
+      GemmArgs a = base_args(p, slot0, nb);
+      a.A = P0; a.sA = Np * NB; a.lda = NB;
+      a.B = M0 + j0 * Np + j0;  // M_jj stored [k][n]
+      a.C = M0 + r0 * Np + j0;
+      a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = NB; a.alpha = -1.0;
+      p.timer.begin(st, ST_TRTRI_B);
+      launch_gemm(st, a, true, false, 64);
+      p.timer.end(st);
+      p.timer.work(ST_TRTRI_B, 2.0 * nb * (double)rem * NB * NB, 0.0);
+    }
+  }
+}
+
+void lauum(Problem& p, hipStream_t st, int slot0, int nb) {
+  const int64_t Np = p.Npad, mat = Np * Np;
+  GemmArgs a = base_args(p, slot0, nb);
+  a.A = p.Mbuf + (int64_t)slot0 * mat;  // A(m, l) = M[l][m]
+  a.B = p.Mbuf + (int64_t)slot0 * mat;  // B(n, l) = M[l][n]
+  a.C = p.Kbuf + (int64_t)slot0 * mat;
+  a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.kmode = 2; a.koff = 0;
+  a.tri = 1; a.tri_off = 0;
+  p.timer.begin(st, ST_LAUUM);
+  launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
+  p.timer.end(st);
+  p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
+}
+
+}  // namespace wv

@@ -1,0 +1,161 @@
+// Bring-up / test hooks (include/waveome_amd_debug.h). Not on the product path.
+#include <cstring>
+#include <vector>
+
+#include "../../include/waveome_amd_debug.h"
+#include "wv_device.hpp"
+
+namespace wv {
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma_rate_kernel(double* out, int iters) {
+  d4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+}  // namespace wv
+
+using namespace wv;
+
+struct wv_ctx { Ctx c; };
+struct wv_problem { Problem p; };
+
+extern "C" {
+
+int32_t wv_dbg_gemm(wv_ctx* ctx, const double* A, const double* B, double* C, int32_t M, int32_t N,
+                    int32_t K, int32_t a_kc, int32_t b_kc, int32_t bn, double alpha, double beta,
+                    int32_t nbatch) {
+  if (!ctx || !A || !B || !C || M < 2 || N < 2 || K < 16 || (K % 16) || (M % 2) || (N % 2) ||
+      (bn != 64 && bn != 128) || nbatch < 1) {
+    set_error("wv_dbg_gemm: bad argument");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  double *dA, *dB, *dC;
+  size_t sa = sizeof(double) * M * K, sb = sizeof(double) * N * K, sc = sizeof(double) * M * N;
+  WV_HIP_TRY(hipMalloc(&dA, sa * nbatch));
+  WV_HIP_TRY(hipMalloc(&dB, sb * nbatch));
+  WV_HIP_TRY(hipMalloc(&dC, sc * nbatch));
+  WV_HIP_TRY(hipMemcpy(dA, A, sa * nbatch, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(dB, B, sb * nbatch, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(dC, C, sc * nbatch, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.A = dA; g.B = dB; g.C = dC;
+  g.sA = (int64_t)M * K; g.sB = (int64_t)N * K; g.sC = (int64_t)M * N;
+  g.lda = a_kc ? K : M; g.ldb = b_kc ? K : N; g.ldc = N;
+  g.M = M; g.N = N; g.kb = 0; g.ke = K; g.alpha = alpha; g.beta = beta; g.nbatch = nbatch;
+  launch_gemm(nullptr, g, a_kc != 0, b_kc != 0, bn);
+  WV_HIP_TRY(hipGetLastError());
+  WV_HIP_TRY(hipDeviceSynchronize());
+  WV_HIP_TRY(hipMemcpy(C, dC, sc * nbatch, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  return WV_OK;
+}
+
+int64_t wv_dbg_npad(const wv_problem* h) { return h ? h->p.Npad : 0; }
+
+int32_t wv_dbg_stage(wv_problem* h, int32_t col, const double* theta, int32_t what, double* out) {
+  if (!h || !theta || !out || col < 0 || col >= h->p.P || what < 0 || what > 4) {
+    set_error("wv_dbg_stage: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  Group& g = p.groups[0];
+  hipStream_t st = g.stream;
+  const int np = p.spec.n_params();
+  std::memcpy(g.h_theta, theta, sizeof(double) * np);
+  g.h_col[0] = col;
+  WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np, g.h_theta, sizeof(double) * np, hipMemcpyHostToDevice, st));
+  WV_HIP_TRY(hipMemcpyAsync(p.dcol + g.slot0, g.h_col, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  launch_resid(p, st, g.slot0, 1);
+  launch_gram(p, st, g.slot0, 1, 0);
+  cholesky(p, st, g.slot0, 1);
+  const int64_t mat = p.Npad * p.Npad;
+  const double* src = nullptr;
+  size_t bytes = sizeof(double) * mat;
+  if (what == 0) src = p.Kbuf + (int64_t)g.slot0 * mat;
+  if (what >= 1) {
+    trtri(p, st, g.slot0, 1);
+    src = p.Mbuf + (int64_t)g.slot0 * mat;
+  }
+  if (what >= 2) {
+    launch_solve(p, st, g.slot0, 1, true);
+    lauum(p, st, g.slot0, 1);
+    src = p.Kbuf + (int64_t)g.slot0 * mat;
+  }
+  if (what == 3) { src = p.dz + (int64_t)g.slot0 * p.Npad; bytes = sizeof(double) * p.Npad; }
+  if (what == 4) { src = p.dalpha + (int64_t)g.slot0 * p.Npad; bytes = sizeof(double) * p.Npad; }
+  WV_HIP_TRY(hipGetLastError());
+  WV_HIP_TRY(hipStreamSynchronize(st));
+  WV_HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return WV_OK;
+}
+
+int32_t wv_dbg_mfma_f64_rate(wv_ctx* ctx, int32_t iters, int32_t wps, double* tflops_out, double* ms_out) {
+  if (!ctx || iters < 1 || wps < 1 || wps > 8) {
+    set_error("wv_dbg_mfma_f64_rate: bad argument");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  const int cus = ctx->c.prop.multiProcessorCount;
+  const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
+  double* d;
+  WV_HIP_TRY(hipMalloc(&d, sizeof(double) * blocks * 256));
+  hipEvent_t a, b;
+  WV_HIP_TRY(hipEventCreate(&a));
+  WV_HIP_TRY(hipEventCreate(&b));
+  hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters / 8 + 1);  // warm
+  WV_HIP_TRY(hipEventRecord(a, nullptr));
+  hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+  WV_HIP_TRY(hipEventRecord(b, nullptr));
+  WV_HIP_TRY(hipEventSynchronize(b));
+  float ms = 0;
+  WV_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  double flops = (double)blocks * 4.0 * iters * 16.0 * 2.0 * 16 * 16 * 4;
+  if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+  if (ms_out) *ms_out = ms;
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(d);
+  return WV_OK;
+}
+
+int32_t wv_dbg_copy_rate(wv_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out) {
+  if (!ctx || bytes < 1024 || iters < 1) {
+    set_error("wv_dbg_copy_rate: bad argument");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  double2 *s, *d;
+  WV_HIP_TRY(hipMalloc(&s, bytes));
+  WV_HIP_TRY(hipMalloc(&d, bytes));
+  WV_HIP_TRY(hipMemset(s, 1, bytes));
+  hipEvent_t a, b;
+  WV_HIP_TRY(hipEventCreate(&a));
+  WV_HIP_TRY(hipEventCreate(&b));
+  int64_t n = bytes / 16;
+  hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, nullptr, s, d, n);
+  WV_HIP_TRY(hipEventRecord(a, nullptr));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, nullptr, s, d, n);
+  WV_HIP_TRY(hipEventRecord(b, nullptr));
+  WV_HIP_TRY(hipEventSynchronize(b));
+  float ms = 0;
+  WV_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  if (gbps_out) *gbps_out = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(s); hipFree(d);
+  return WV_OK;
+}
+}

@@ -1,0 +1,168 @@
+// Shared declarations of the device path (gfx950 only).
+//
+// HBM layout per problem (all float64, row-major):
+//   X      [Npad][D]         design matrix, padded rows are zero
+//   Y      [P][Npad]         one contiguous row per output column, padding zero
+// per batch slot s (max_batch slots):
+//   Kbuf   [Npad][Npad]      K_y (lower) -> L (lower, in place) -> K_y^-1 (lower)
+//   Mbuf   [Npad][Npad]      M = L^-1 (lower; strictly upper part stays zero)
+//   Pbuf   [Npad][64]        TRTRI panel temporary
+//   theta  [n_params]        constrained parameter table of the slot's fit
+//   r, z, alpha [Npad]       residual y - c, L^-1 r, K_y^-1 r
+// Npad = N rounded up to a multiple of 64; padded rows/cols of K_y are the identity so
+// log|K_y|, r' K_y^-1 r and the leading N x N block of K_y^-1 are unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "wv_spec.hpp"
+
+namespace wv {
+
+constexpr int NB = 64;          // diagonal block / panel width
+constexpr int GT = 64;          // Gram / trace tile edge
+constexpr int MAX_FEAT = 64;    // feature slots per side staged in LDS by the Gram kernels
+constexpr int MAX_TERM_F = 4;   // factors per term
+
+// ---- device-side spec --------------------------------------------------------------
+struct DevFactor {
+  int32_t type;
+  int32_t p[3];       // parameter indices
+  int32_t degree;
+  int32_t ndims;
+  int32_t slot0;      // first feature slot (see FeatOp); consecutive per active dim
+  int32_t trainable;  // bit k set: parameter k of this factor is trainable
+};
+enum { FEAT_RAW = 0, FEAT_RINT = 1, FEAT_SINPI = 2, FEAT_COSPI = 3 };
+struct FeatOp {
+  int32_t kind;
+  int32_t dim;
+  int32_t param;  // period parameter for SINPI/COSPI
+  int32_t pad;
+};
+struct DevSpec {
+  int32_t n_terms, n_factors, n_feat, n_params;
+  int32_t noise_param, mean_param, n_dims, pad;
+  int32_t term_start[65];
+  DevFactor factors[128];
+  FeatOp feat[MAX_FEAT];
+  int16_t fslots[512];  // per factor: feature slot per active dim (Periodic: sin, cos, raw)
+};
+
+// ---- GEMM launch description --------------------------------------------------------
+// C[m][n] = beta*C[m][n] + alpha * sum_{k in [kb,ke)} A(m,k) * B(n,k),  per batch slot.
+// A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m];  B(n,k) likewise.
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t sA, sB, sC;  // batch strides (elements)
+  int32_t lda, ldb, ldc;
+  int32_t M, N;        // extent of C
+  int32_t kb, ke;      // default contraction range
+  // kmode 0: [kb, ke).  1: [kb, min(ke, m0 + BM + koff))  (triangular A, TRTRI)
+  //       2: [max(kb, m0 + koff), ke)                    (LAUUM)
+  int32_t kmode, koff;
+  int32_t tri;         // 1: skip tiles whose first column (n0 + tri_off) > last row (m0 + BM - 1)
+  int32_t tri_off;
+  double alpha, beta;
+  int32_t nbatch;
+  int32_t tiles_m, tiles_n;
+};
+
+enum Stage {
+  ST_GRAM = 0, ST_POTRF_DIAG, ST_CHOL_TRSM, ST_CHOL_PANEL, ST_CHOL_TRAIL, ST_TRTRI_A, ST_TRTRI_B,
+  ST_LAUUM, ST_SOLVE, ST_TRACE, ST_REDUCE, ST_COUNT
+};
+extern const char* const kStageNames[ST_COUNT];
+
+struct StageTimer {
+  bool enabled = false;
+  struct Rec { hipEvent_t a, b; int stage; };
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[ST_COUNT] = {0};
+  int64_t launches[ST_COUNT] = {0};
+  double flops[ST_COUNT] = {0};
+  double bytes[ST_COUNT] = {0};
+  void begin(hipStream_t s, int stage);
+  void end(hipStream_t s);
+  void collect();
+  void reset();
+  void work(int stage, double fl, double by) { if (enabled) { flops[stage] += fl; bytes[stage] += by; } }
+  ~StageTimer();
+};
+
+struct Ctx {
+  int device = 0;
+  hipDeviceProp_t prop;
+};
+
+// One group = a set of batch slots that advance together on one stream.
+struct Group {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int slot0 = 0, nslots = 0;
+  // pinned host staging
+  double* h_theta = nullptr;   // [nslots][n_params]
+  int32_t* h_col = nullptr;    // [nslots]
+  double* h_out = nullptr;     // [nslots][out_stride]
+  int32_t* h_status = nullptr; // [nslots]
+};
+
+struct Problem {
+  Ctx* ctx = nullptr;
+  Spec spec;
+  DevSpec hspec;
+  int64_t N = 0, Npad = 0;
+  int D = 0, P = 0, max_batch = 0;
+  int out_stride = 0;  // doubles per slot in the result record
+  // device memory
+  double *dX = nullptr, *dY = nullptr;
+  DevSpec* dspec = nullptr;
+  double *Kbuf = nullptr, *Mbuf = nullptr, *Pbuf = nullptr;
+  double *dtheta = nullptr, *dr = nullptr, *dz = nullptr, *dalpha = nullptr;
+  double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
+  double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials
+  double *dout = nullptr;      // [max_batch][out_stride]
+  int32_t *dcol = nullptr, *dstatus = nullptr;
+  int64_t workspace_bytes = 0;
+  std::vector<Group> groups;
+  StageTimer timer;
+  int nblk() const { return (int)(Npad / NB); }
+  int ntiles() const { int t = (int)(Npad / GT); return t * (t + 1) / 2; }
+};
+
+// result record layout per slot: [0]=lml, [1]=quad(z'z), [2]=logdet, [3..3+n_params)=dLML/dtheta
+inline int out_stride_for(int n_params) { return 3 + n_params; }
+
+// ---- kernel launchers (each enqueues on `st`, no host sync) ---------------------------
+void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper);
+void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0);
+void launch_gemm(hipStream_t st, const GemmArgs& a, bool a_kcontig, bool b_kcontig, int bn);
+void launch_resid(Problem& p, hipStream_t st, int slot0, int nb);
+void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha);
+void launch_trace(Problem& p, hipStream_t st, int slot0, int nb);
+void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad);
+int trace_nwg(const Problem& p);
+
+// schedules
+void cholesky(Problem& p, hipStream_t st, int slot0, int nb);
+void trtri(Problem& p, hipStream_t st, int slot0, int nb);
+void lauum(Problem& p, hipStream_t st, int slot0, int nb);
+
+std::string build_devspec(const Spec& s, DevSpec& out);
+
+#define WV_HIP_TRY(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      wv::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+      return WV_E_HIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+}  // namespace wv

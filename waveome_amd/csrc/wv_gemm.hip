@@ -1,0 +1,193 @@
+// Batched float64 GEMM family on v_mfma_f64_16x16x4_f64 (gfx950).
+//
+// One kernel template serves every O(N^3) step of the evaluation:
+//   NT  C -= L21 L21'          Cholesky trailing / panel updates, TRSM via inv(L11)
+//   NN  P  = M22 L21, M21 = -P Mkk     triangular inversion by block columns
+//   TN  K^-1 = M' M            inverse from the triangular inverse
+// (reference: the tf.linalg.cholesky / triangular_solve / matmul TensorFlow issues, forward and
+//  reverse mode, for gpflow's log marginal likelihood - waveome/model_types_DEPR.py:49-56.)
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x BN (BN = 128 or 64), K chunk 16.
+// Each wave owns 64 x BN/2 outputs = 4 x BN/32 MFMA accumulators (4 f64 per lane each).
+// Operand tiles are staged global -> registers -> LDS, double-buffered, one barrier per chunk.
+// LDS images are laid out so the MFMA fragment reads (lane l: row l&15, k = l>>4) are
+// bank-conflict free with ds_read_b64:
+//   K-contiguous operand  [rows][16+2]   (row stride 18 doubles: 18*r mod 32 distinct, even)
+//   K-strided   operand   [16][rows+16]  (row stride = 16 mod 32 doubles)
+// f64 MFMA C/D map (differs from every other dtype): col = lane & 15, row = (lane >> 4) + 4*reg.
+#include "wv_device.hpp"
+
+namespace wv {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128;
+constexpr int KC = 16;
+
+template <int ROWS, bool KCONTIG>
+struct Tile {
+  static constexpr int LD = KCONTIG ? (KC + 2) : (ROWS + 16);
+  static constexpr int SIZE = KCONTIG ? ROWS * LD : KC * LD;
+  static constexpr int NLOAD = ROWS / 32;  // double2 loads per thread per chunk
+  __device__ static inline int at(int row, int k) { return KCONTIG ? row * LD + k : k * LD + row; }
+
+  // global -> registers. base points at element (row 0, k 0) of the operand for this batch.
+  __device__ static inline void gload(d2 (&reg)[NLOAD], const double* __restrict__ base, int ld,
+                                      int row0, int nrows, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int q = tid + 256 * i;
+      d2 v = {0.0, 0.0};
+      if (KCONTIG) {
+        int row = q >> 3, kp = q & 7;
+        if (row0 + row < nrows)
+          v = *reinterpret_cast<const d2*>(base + (int64_t)(row0 + row) * ld + k0 + 2 * kp);
+      } else {
+        int k = q / (ROWS / 2), rp = q % (ROWS / 2);
+        if (row0 + 2 * rp < nrows)
+          v = *reinterpret_cast<const d2*>(base + (int64_t)(k0 + k) * ld + row0 + 2 * rp);
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ static inline void sstore(double* __restrict__ s, const d2 (&reg)[NLOAD], int tid) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int q = tid + 256 * i;
+      if (KCONTIG) {
+        int row = q >> 3, kp = q & 7;
+        *reinterpret_cast<d2*>(s + row * LD + 2 * kp) = reg[i];
+      } else {
+        int k = q / (ROWS / 2), rp = q % (ROWS / 2);
+        *reinterpret_cast<d2*>(s + k * LD + 2 * rp) = reg[i];
+      }
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+  using TA = Tile<BM, A_KC>;
+  using TB = Tile<BN, B_KC>;
+  constexpr int NJ = BN / 32;  // B fragments per wave
+  __shared__ __attribute__((aligned(16))) double sA[2][TA::SIZE];
+  __shared__ __attribute__((aligned(16))) double sB[2][TB::SIZE];
+
+  // ---- block -> (batch, tile) with same-matrix tiles kept on one XCD (L2 reuse of panels) ----
+  const int tiles = g.tiles_m * g.tiles_n;
+  int b, tile;
+  if (g.nbatch >= 8) {
+    int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    b = xcd + 8 * (q / tiles);
+    tile = q % tiles;
+    if (b >= g.nbatch) return;
+  } else {
+    b = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (g.tri && n0 + g.tri_off > m0 + BM - 1) return;
+
+  int kb = g.kb, ke = g.ke;
+  if (g.kmode == 1) ke = min(ke, m0 + BM + g.koff);
+  if (g.kmode == 2) kb = max(kb, m0 + g.koff);
+
+  const double* __restrict__ A = g.A + (int64_t)b * g.sA;
+  const double* __restrict__ B = g.B + (int64_t)b * g.sB;
+  double* __restrict__ C = g.C + (int64_t)b * g.sC;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  d4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[TA::NLOAD], rb[TB::NLOAD];
+  const int nchunk = (ke - kb) / KC;
+  if (nchunk > 0) {
+    TA::gload(ra, A, g.lda, m0, g.M, kb, tid);
+    TB::gload(rb, B, g.ldb, n0, g.N, kb, tid);
+    TA::sstore(sA[0], ra, tid);
+    TB::sstore(sB[0], rb, tid);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunk) {
+      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * KC, tid);
+      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * KC, tid);
+    }
+    const double* __restrict__ a_s = sA[cur];
+    const double* __restrict__ b_s = sB[cur];
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+      double af[4], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = b_s[TB::at(wn * (BN / 2) + j * 16 + fr, s * 4 + fk)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) {
+      TA::sstore(sA[cur ^ 1], ra, tid);
+      TB::sstore(sB[cur ^ 1], rb, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C = beta*C + alpha*acc (rows (lane>>4)+4*reg, col lane&15 of each 16x16) ----
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + fk + 4 * r;
+        if (m < g.M && n < g.N) {
+          double* cp = C + (int64_t)m * g.ldc + n;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * (*cp);
+          *cp = v;
+        }
+      }
+    }
+  }
+}
+
+void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int bn) {
+  GemmArgs a = a_in;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + bn - 1) / bn;
+  if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
+  int tiles = a.tiles_m * a.tiles_n;
+  int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
+  dim3 g(grid), blk(256);
+#define WV_LAUNCH(AK, BK, BNN) \
+  hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN>), g, blk, 0, st, a)
+  if (bn == 128) {
+    if (a_kc && b_kc) WV_LAUNCH(true, true, 128);
+    else if (a_kc && !b_kc) WV_LAUNCH(true, false, 128);
+    else if (!a_kc && !b_kc) WV_LAUNCH(false, false, 128);
+    else WV_LAUNCH(false, true, 128);
+  } else {
+    if (a_kc && b_kc) WV_LAUNCH(true, true, 64);
+    else if (a_kc && !b_kc) WV_LAUNCH(true, false, 64);
+    else if (!a_kc && !b_kc) WV_LAUNCH(false, false, 64);
+    else WV_LAUNCH(false, true, 64);
+  }
+#undef WV_LAUNCH
+}
+
+}  // namespace wv

@@ -1,0 +1,255 @@
+#include "wv_spec.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "wv_lbfgs.hpp"
+
+namespace wv {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+int n_factor_params(int type) {
+  switch (type) {
+    case WV_K_SE:
+    case WV_K_M12:
+    case WV_K_M32:
+    case WV_K_M52:
+    case WV_K_POLY:
+      return 2;
+    case WV_K_PERIODIC:
+      return 3;
+    case WV_K_LIN:
+    case WV_K_CONST:
+    case WV_K_CAT:
+      return 1;
+    case WV_K_EMPTY:
+      return 0;
+    default:
+      return -1;
+  }
+}
+
+double softplus(double u) { return u > 0 ? u + std::log1p(std::exp(-u)) : std::log1p(std::exp(u)); }
+double inv_softplus(double x) { return x + std::log(-std::expm1(-x)); }
+double sigmoid(double u) { return 0.5 * (1.0 + std::tanh(0.5 * u)); }
+
+// tfd.Horseshoe._log_prob restated (see oracle/gp_oracle.py: horseshoe_logpdf).
+double horseshoe_logpdf(double x, double scale, double* dlogp) {
+  const double g = 0.5614594835668851, b = 1.0420764938351215, h_inf = 1.0801359952503342;
+  const double pw = 1.0919284281983377;
+  double xx = (x / scale) * (x / scale) / 2.0;
+  double q = 20.0 / 47.0 * std::pow(xx, pw);
+  double x15 = std::pow(xx, 1.5);
+  double h = 1.0 / (1.0 + x15) + h_inf * q / (1.0 + q);
+  double c = -0.5 * std::log(2.0 * M_PI * M_PI * M_PI) - std::log(g * scale);
+  double z = std::log1p(-g) - std::log(g);
+  double t = z - xx / (1.0 - g);
+  double den = h + b * xx;
+  double inner = g / xx - (1.0 - g) / (den * den);
+  double l1p = std::log1p(inner);
+  if (dlogp) {
+    double dxx = x / (scale * scale);
+    double dq = 20.0 / 47.0 * pw * std::pow(xx, pw - 1.0);
+    double dh = -1.5 * std::sqrt(xx) / ((1.0 + x15) * (1.0 + x15)) + h_inf * dq / ((1.0 + q) * (1.0 + q));
+    double d1 = sigmoid(t) / (1.0 - g);
+    double dinner = -g / (xx * xx) + 2.0 * (1.0 - g) * (dh + b) / (den * den * den);
+    *dlogp = (d1 + dinner / ((1.0 + inner) * l1p)) * dxx;
+  }
+  return -softplus(t) + std::log(l1p) + c;
+}
+
+std::string Spec::parse(const wv_kernel_spec* s, Spec& out) {
+  if (!s) return "spec is NULL";
+  if (s->n_dims < 1 || s->n_dims > WV_MAX_DIMS) return "n_dims out of range [1, 32]";
+  if (s->n_params < 1 || s->n_params > WV_MAX_PARAMS) return "n_params out of range";
+  if (!s->params || !s->term_start || (s->n_terms > 0 && !s->factors)) return "null table in spec";
+  if (s->n_terms < 0) return "n_terms < 0";
+  out = Spec();
+  out.n_dims = s->n_dims;
+  out.params.assign(s->params, s->params + s->n_params);
+  out.term_start.assign(s->term_start, s->term_start + s->n_terms + 1);
+  if (out.term_start[0] != 0) return "term_start[0] != 0";
+  for (int t = 0; t < s->n_terms; ++t)
+    if (out.term_start[t + 1] <= out.term_start[t]) return "empty or unordered term";
+  int nf = out.term_start[s->n_terms];
+  out.factors.assign(s->factors, s->factors + nf);
+  uint32_t all = s->n_dims == 32 ? 0xffffffffu : ((1u << s->n_dims) - 1u);
+  for (const auto& f : out.factors) {
+    int np = n_factor_params(f.type);
+    if (np < 0) return "unknown factor type";
+    if (f.type != WV_K_EMPTY && f.type != WV_K_CONST) {
+      if (f.dim_mask == 0 || (f.dim_mask & ~all)) return "factor dim_mask outside the D columns";
+    }
+    if (f.type == WV_K_CAT && __builtin_popcount(f.dim_mask) != 1)
+      return "categorical factor needs exactly one column";
+    if (f.type == WV_K_POLY && (f.degree < 1 || f.degree > 16)) return "poly degree out of range";
+    for (int k = 0; k < np; ++k)
+      if (f.param[k] < 0 || f.param[k] >= s->n_params) return "factor parameter index out of range";
+  }
+  if (s->noise_param < 0 || s->noise_param >= s->n_params) return "noise_param out of range";
+  if (s->mean_param < -1 || s->mean_param >= s->n_params) return "mean_param out of range";
+  out.noise_param = s->noise_param;
+  out.mean_param = s->mean_param;
+  for (int i = 0; i < s->n_params; ++i) {
+    const auto& p = out.params[i];
+    if (p.transform < WV_T_IDENTITY || p.transform > WV_T_SOFTPLUS_SHIFT) return "unknown transform";
+    if (p.transform == WV_T_SOFTPLUS && !(p.init > 0)) return "positive parameter with init <= 0";
+    if (p.transform == WV_T_SOFTPLUS_SHIFT && !(p.init > kNoiseFloor))
+      return "noise variance init <= 1e-6";
+    if (p.trainable) out.trainable.push_back(i);
+  }
+  return "";
+}
+
+void Spec::constrain(const double* u, double* theta) const {
+  for (int i = 0; i < n_params(); ++i) theta[i] = params[i].init;
+  for (int k = 0; k < n_trainable(); ++k) {
+    int i = trainable[k];
+    switch (params[i].transform) {
+      case WV_T_SOFTPLUS:
+        theta[i] = softplus(u[k]);
+        break;
+      case WV_T_SOFTPLUS_SHIFT:
+        theta[i] = kNoiseFloor + softplus(u[k]);
+        break;
+      default:
+        theta[i] = u[k];
+    }
+  }
+}
+
+void Spec::unconstrain(const double* theta, double* u) const {
+  for (int k = 0; k < n_trainable(); ++k) {
+    int i = trainable[k];
+    switch (params[i].transform) {
+      case WV_T_SOFTPLUS:
+        u[k] = inv_softplus(theta[i]);
+        break;
+      case WV_T_SOFTPLUS_SHIFT:
+        u[k] = inv_softplus(theta[i] - kNoiseFloor);
+        break;
+      default:
+        u[k] = theta[i];
+    }
+  }
+}
+
+double Spec::dconstrain(int k, double u) const {
+  int t = params[trainable[k]].transform;
+  return (t == WV_T_IDENTITY) ? 1.0 : sigmoid(u);
+}
+
+double Spec::log_prior(const double* theta, double* grad) const {
+  double tot = 0;
+  if (grad) std::memset(grad, 0, sizeof(double) * n_params());
+  for (int i = 0; i < n_params(); ++i) {
+    const auto& p = params[i];
+    if (p.trainable && p.prior_scale > 0) {
+      double d = 0;
+      tot += horseshoe_logpdf(theta[i], p.prior_scale, grad ? &d : nullptr);
+      if (grad) grad[i] = d;
+    }
+  }
+  return tot;
+}
+
+}  // namespace wv
+
+// ---------------- C-ABI: host-only entry points ----------------
+using namespace wv;
+
+extern "C" {
+
+int32_t wv_abi_version(void) { return WV_ABI_VERSION; }
+const char* wv_last_error(void) { return g_err.c_str(); }
+
+void wv_lbfgs_default_opts(wv_lbfgs_opts* o) {
+  if (!o) return;
+  o->m = 10;
+  o->maxiter = 50000;  // waveome/model_classes.py:310-313
+  o->maxfun = 50000;
+  o->maxls = 20;
+  o->ftol = 2.220446049250313e-09;
+  o->gtol = 1e-05;
+}
+
+int32_t wv_spec_check(const wv_kernel_spec* spec, int32_t* n_trainable_out) {
+  Spec s;
+  std::string e = Spec::parse(spec, s);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (n_trainable_out) *n_trainable_out = s.n_trainable();
+  return WV_OK;
+}
+
+int32_t wv_spec_constrain(const wv_kernel_spec* spec, const double* u, double* theta_out) {
+  Spec s;
+  std::string e = Spec::parse(spec, s);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (!u || !theta_out) {
+    set_error("null argument");
+    return WV_E_BADARG;
+  }
+  s.constrain(u, theta_out);
+  return WV_OK;
+}
+
+int32_t wv_spec_unconstrain(const wv_kernel_spec* spec, const double* theta, double* u_out) {
+  Spec s;
+  std::string e = Spec::parse(spec, s);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (!theta || !u_out) {
+    set_error("null argument");
+    return WV_E_BADARG;
+  }
+  s.unconstrain(theta, u_out);
+  return WV_OK;
+}
+
+int32_t wv_spec_log_prior(const wv_kernel_spec* spec, const double* theta, double* value_out,
+                          double* grad_out) {
+  Spec s;
+  std::string e = Spec::parse(spec, s);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (!theta || !value_out) {
+    set_error("null argument");
+    return WV_E_BADARG;
+  }
+  *value_out = s.log_prior(theta, grad_out);
+  return WV_OK;
+}
+
+struct wv_lbfgs {
+  Lbfgs impl;
+  wv_lbfgs(int n, const wv_lbfgs_opts& o, const double* x0) : impl(n, o, x0) {}
+};
+
+int32_t wv_lbfgs_create(int32_t n, const wv_lbfgs_opts* opts, const double* x0, wv_lbfgs** out) {
+  if (n < 1 || !opts || !x0 || !out) {
+    set_error("wv_lbfgs_create: bad argument");
+    return WV_E_BADARG;
+  }
+  *out = new wv_lbfgs(n, *opts, x0);
+  return WV_OK;
+}
+const double* wv_lbfgs_x(const wv_lbfgs* s) { return s->impl.x(); }
+int32_t wv_lbfgs_feed(wv_lbfgs* s, double f, const double* g) { return s->impl.feed(f, g); }
+int32_t wv_lbfgs_n_iter(const wv_lbfgs* s) { return s->impl.n_iter(); }
+int32_t wv_lbfgs_n_eval(const wv_lbfgs* s) { return s->impl.n_eval(); }
+double wv_lbfgs_f(const wv_lbfgs* s) { return s->impl.f(); }
+void wv_lbfgs_destroy(wv_lbfgs* s) { delete s; }
+
+}  // extern "C"

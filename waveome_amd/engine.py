@@ -1,0 +1,177 @@
+"""Thin Python handles over the C-ABI device path (include/waveome_amd.h).
+
+`Context` = one GPU; `Problem` = (X, Y, kernel spec) resident in HBM with workspace for
+`max_batch` fits in flight.  All heavy work happens in libwaveome_amd.so; these classes only
+marshal NumPy arrays.  There is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .spec import ModelSpec
+
+
+def lbfgs_opts(maxiter=50000, maxfun=None, ftol=2.220446049250313e-09, gtol=1e-05, m=10, maxls=20):
+    """SciPy L-BFGS-B option set; defaults = the reference's (waveome/model_classes.py:310-313)."""
+    o = _lib.LbfgsOpts()
+    o.m, o.maxiter, o.maxfun, o.maxls = int(m), int(maxiter), int(maxfun or maxiter), int(maxls)
+    o.ftol, o.gtol = float(ftol), float(gtol)
+    return o
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.wv_ctx_create(int(device), 0, C.byref(self.handle)), "wv_ctx_create")
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            self.lib.wv_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- bring-up probes (include/waveome_amd_debug.h) ----
+    def mfma_f64_rate(self, iters=20000, waves_per_simd=1):
+        tf, ms = C.c_double(), C.c_double()
+        _lib.check(self.lib.wv_dbg_mfma_f64_rate(self.handle, iters, waves_per_simd, C.byref(tf),
+                                                 C.byref(ms)), "wv_dbg_mfma_f64_rate")
+        return tf.value, ms.value
+
+    def copy_rate(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        _lib.check(self.lib.wv_dbg_copy_rate(self.handle, int(nbytes), iters, C.byref(g)), "wv_dbg_copy_rate")
+        return g.value
+
+    def dbg_gemm(self, A, B, Cm, a_kcontig=True, b_kcontig=True, bn=128, alpha=1.0, beta=0.0):
+        """A: [nb, M, K] (or [nb, K, M] if not a_kcontig); B likewise; Cm: [nb, M, N] updated copy."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        out = np.array(Cm, dtype=np.float64, order="C", copy=True)
+        nb, M, N = out.shape
+        K = A.shape[2] if a_kcontig else A.shape[1]
+        _lib.check(self.lib.wv_dbg_gemm(self.handle, _lib.as_dp(A), _lib.as_dp(B), _lib.as_dp(out), M, N, K,
+                                        int(a_kcontig), int(b_kcontig), bn, alpha, beta, nb), "wv_dbg_gemm")
+        return out
+
+
+class Problem:
+    def __init__(self, ctx: Context, X, Y, spec: ModelSpec, max_batch: int = 8,
+                 x_device_ptr: Optional[int] = None, y_device_ptr: Optional[int] = None,
+                 shape: Optional[Sequence[int]] = None):
+        """X: (N, D) array, Y: (N, P) array (one column per output).  Alternatively pass raw device
+        pointers (x_device_ptr -> N x D row-major, y_device_ptr -> P x N row-major) with
+        shape=(N, D, P), e.g. buffers filled by an RCCL broadcast."""
+        self.ctx, self.lib, self.spec = ctx, ctx.lib, spec
+        self._cspec = spec.to_ctypes()
+        self.handle = C.c_void_p()
+        if x_device_ptr is not None:
+            N, D, P = (int(v) for v in shape)
+            xp, yp, xd, yd = C.c_void_p(x_device_ptr), C.c_void_p(y_device_ptr), 1, 1
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            Y = np.asarray(Y, dtype=np.float64)
+            if Y.ndim == 1:
+                Y = Y[:, None]
+            N, D = X.shape
+            if Y.shape[0] != N:
+                raise ValueError("X and Y disagree on N")
+            P = Y.shape[1]
+            self._Yt = np.ascontiguousarray(Y.T)
+            self._X = X
+            xp, yp, xd, yd = C.c_void_p(X.ctypes.data), C.c_void_p(self._Yt.ctypes.data), 0, 0
+        self.N, self.D, self.P, self.max_batch = N, D, P, int(max_batch)
+        _lib.check(self.lib.wv_problem_create(ctx.handle, xp, N, D, yp, P, C.byref(self._cspec),
+                                              int(max_batch), xd, yd, C.byref(self.handle)),
+                   "wv_problem_create")
+        self.n_params = spec.n_params
+        self.n_trainable = spec.n_trainable
+
+    def close(self):
+        if self.handle:
+            self.lib.wv_problem_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.wv_problem_workspace_bytes(self.handle))
+
+    def gram(self, theta) -> np.ndarray:
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        K = np.empty((self.N, self.N))
+        _lib.check(self.lib.wv_gram(self.handle, _lib.as_dp(theta), _lib.as_dp(K)), "wv_gram")
+        return K
+
+    def lml(self, cols, thetas):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B = len(cols)
+        out, st = np.empty(B), np.empty(B, dtype=np.int32)
+        _lib.check(self.lib.wv_lml(self.handle, _lib.as_ip(cols), B, _lib.as_dp(thetas), _lib.as_dp(out),
+                                   _lib.as_ip(st)), "wv_lml")
+        return out, st
+
+    def value_grad(self, cols, U):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        U = np.ascontiguousarray(np.atleast_2d(U), dtype=np.float64)
+        B = len(cols)
+        loss, grad, st = np.empty(B), np.empty((B, self.n_trainable)), np.empty(B, dtype=np.int32)
+        _lib.check(self.lib.wv_value_grad(self.handle, _lib.as_ip(cols), B, _lib.as_dp(U), _lib.as_dp(loss),
+                                          _lib.as_dp(grad), _lib.as_ip(st)), "wv_value_grad")
+        return loss, grad, st
+
+    def fit(self, cols, U0, opts=None):
+        """Fit len(cols) tasks; returns dict of arrays (u, loss, lml, nit, nfev, status)."""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        U = np.array(np.atleast_2d(U0), dtype=np.float64, order="C", copy=True)
+        T = len(cols)
+        if U.shape != (T, self.n_trainable):
+            raise ValueError(f"U0 must be ({T}, {self.n_trainable})")
+        opts = opts or lbfgs_opts()
+        loss, lml = np.empty(T), np.empty(T)
+        nit, nfev, st = (np.empty(T, dtype=np.int32) for _ in range(3))
+        _lib.check(self.lib.wv_fit(self.handle, _lib.as_ip(cols), T, C.byref(opts), _lib.as_dp(U),
+                                   _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit), _lib.as_ip(nfev),
+                                   _lib.as_ip(st)), "wv_fit")
+        return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
+
+    # ---- timing ----
+    def timing(self, on: bool):
+        self.lib.wv_stage_timing_enable(self.handle, 1 if on else 0)
+
+    def timing_reset(self):
+        self.lib.wv_stage_times_reset(self.handle)
+
+    def stage_times(self):
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms, fl, by = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        ln = np.zeros(cap, dtype=np.int64)
+        n = self.lib.wv_stage_times(self.handle, cap, names, _lib.as_dp(ms),
+                                    ln.ctypes.data_as(C.POINTER(C.c_int64)), _lib.as_dp(fl), _lib.as_dp(by))
+        return {names[i].decode(): {"ms": float(ms[i]), "launches": int(ln[i]), "flops": float(fl[i]),
+                                    "bytes": float(by[i])} for i in range(n)}
+
+    # ---- bring-up ----
+    def dbg_stage(self, col, theta, what):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        npad = int(self.lib.wv_dbg_npad(self.handle))
+        out = np.empty(npad if what >= 3 else (npad, npad))
+        _lib.check(self.lib.wv_dbg_stage(self.handle, int(col), _lib.as_dp(theta), int(what), _lib.as_dp(out)),
+                   "wv_dbg_stage")
+        return out
