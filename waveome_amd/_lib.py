@@ -87,9 +87,12 @@ SIGNATURES = {
     # include/waveome_amd_debug.h
     "wv_dbg_gemm": (C.c_int32, [_vp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32]),
+    "wv_dbg_gemm_bench": (C.c_int32, [_vp] + [C.c_int32] * 8 + [_dp, _dp]),
     "wv_dbg_stage": (C.c_int32, [_vp, C.c_int32, _dp, C.c_int32, _dp]),
     "wv_dbg_npad": (C.c_int64, [_vp]),
     "wv_dbg_mfma_f64_rate": (C.c_int32, [_vp, C.c_int32, C.c_int32, _dp, _dp]),
+    "wv_dbg_valu_f64_rate": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
+    "wv_dbg_mfma4_probe": (C.c_int32, [_vp, _ip]),
     "wv_dbg_copy_rate": (C.c_int32, [_vp, C.c_int64, C.c_int32, _dp]),
 }
 

@@ -386,15 +386,15 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
   std::memcpy(g.h_theta, theta, sizeof(double) * np);
   WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np, g.h_theta, sizeof(double) * np,
                             hipMemcpyHostToDevice, g.stream));
-  launch_gram(p, g.stream, g.slot0, 1, 1);
+  launch_gram(p, g.stream, g.slot0, 1, 0);
   WV_HIP_TRY(hipGetLastError());
   WV_HIP_TRY(hipMemcpy2DAsync(K_out, sizeof(double) * p.N, p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad,
                               sizeof(double) * p.Npad, sizeof(double) * p.N, p.N,
                               hipMemcpyDeviceToHost, g.stream));
   WV_HIP_TRY(hipStreamSynchronize(g.stream));
-  // the upper triangle of Kbuf must be zero again for the factorisation path
-  WV_HIP_TRY(hipMemsetAsync(p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad, 0, sizeof(double) * p.Npad * p.Npad, g.stream));
-  WV_HIP_TRY(hipStreamSynchronize(g.stream));
+  // the device kernel fills lower tiles only; mirror on the host so the caller sees K_y = K_y'
+  for (int64_t i = 0; i < p.N; ++i)
+    for (int64_t j = i + 1; j < p.N; ++j) K_out[i * p.N + j] = K_out[j * p.N + i];
   return WV_OK;
 }
 

@@ -1,25 +1,37 @@
-// Batched float64 GEMM family on v_mfma_f64_16x16x4_f64 (gfx950).
+// Batched float64 GEMM family on v_mfma_f64_4x4x4_4b_f64 (gfx950).
 //
 // One kernel template serves every O(N^3) step of the evaluation:
 //   NT  C -= L21 L21'          Cholesky trailing / panel updates, TRSM via inv(L11)
-//   NN  P  = M22 L21, M21 = -P Mkk     triangular inversion by block columns
+//   NN  P  = M22 L21, M21 = -P Mkk     triangular inversion
 //   TN  K^-1 = M' M            inverse from the triangular inverse
 // (reference: the tf.linalg.cholesky / triangular_solve / matmul TensorFlow issues, forward and
 //  reverse mode, for gpflow's log marginal likelihood - waveome/model_types_DEPR.py:49-56.)
 //
+// Why the 4x4x4 four-block MFMA: measured on MI355X (tools/probe_rates.py) back-to-back
+// v_mfma_f64_16x16x4_f64 sustains 36 TFLOP/s (128 cycles / instruction) while
+// v_mfma_f64_4x4x4_4b_f64 sustains 73 TFLOP/s (16 cycles / 512 FLOP), i.e. the datasheet's
+// 78.6 TF FP64 matrix rate is only reachable with the four-block form.
+// Lane maps, measured with one-hot operands (tools/probe_mfma4.py); blk = block 0..3:
+//   A_blk[i][k] : lane 16 k + 4 blk + i      B_blk[k][j] : lane 16 k + 4 blk + j
+//   D_blk[i][j] : lane 16 i + 4 blk + j      D_blk = A_blk B_blk + C_blk   (4x4x4 each)
+// A fragment register covers 16 rows x 4 k (block blk = rows 4 blk..4 blk+3), the same
+// lane -> (row, k) map as the 16x16x4 form.  A B fragment covers 16 columns x 4 k; loading it
+// with the column groups rotated by s (block blk holds columns 4((blk+s)&3)..) for s = 0..3
+// pairs every row group with every column group, so 4 A fragments x (4 column sets x 4
+// rotations) = 64 MFMAs fill a 64 x 64 wave tile per k-step of 4.
+//
 // Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x BN (BN = 128 or 64), K chunk 16.
-// Each wave owns 64 x BN/2 outputs = 4 x BN/32 MFMA accumulators (4 f64 per lane each).
 // Operand tiles are staged global -> registers -> LDS, double-buffered, one barrier per chunk.
-// LDS images are laid out so the MFMA fragment reads (lane l: row l&15, k = l>>4) are
+// LDS images keep the fragment reads (lane l: row l&15 permuted within its 16, k = l>>4)
 // bank-conflict free with ds_read_b64:
 //   K-contiguous operand  [rows][16+2]   (row stride 18 doubles: 18*r mod 32 distinct, even)
 //   K-strided   operand   [16][rows+16]  (row stride = 16 mod 32 doubles)
-// f64 MFMA C/D map (differs from every other dtype): col = lane & 15, row = (lane >> 4) + 4*reg.
+#include <cstdlib>
+
 #include "wv_device.hpp"
 
 namespace wv {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128;
@@ -66,8 +78,10 @@ struct Tile {
   }
 };
 
-template <bool A_KC, bool B_KC, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+// OCC = waves per SIMD the register allocator may assume (2: <= 256 VGPRs, two workgroups per CU;
+// 1: up to 512 VGPRs, one workgroup per CU, k-steps fully unrolled and software-pipelined).
+template <bool A_KC, bool B_KC, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
   constexpr int NJ = BN / 32;  // B fragments per wave
@@ -101,12 +115,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
+  // B-fragment column (within its 16) for rotation s: 4*((blk + s) & 3) + j
+  const int fblk = (lane >> 2) & 3, fj = lane & 3;
+  int brot[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) brot[s] = 4 * ((fblk + s) & 3) + fj;
 
-  d4 acc[4][NJ];
+  double acc[4][NJ][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb) / KC;
@@ -125,18 +146,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
-#pragma unroll
+#pragma unroll OCC == 1 ? 4 : 1
     for (int s = 0; s < KC / 4; ++s) {
-      double af[4], bf[NJ];
+      double af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = b_s[TB::at(wn * (BN / 2) + j * 16 + fr, s * 4 + fk)];
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) {
+          const double bf = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 4; ++i)
+            acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+        }
+      }
     }
     if (c + 1 < nchunk) {
       TA::sstore(sA[cur ^ 1], ra, tid);
@@ -145,16 +169,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: C = beta*C + alpha*acc (rows (lane>>4)+4*reg, col lane&15 of each 16x16) ----
+  // ---- epilogue: C = beta*C + alpha*acc.  D lane 16 i' + 4 blk + j of accumulator (i, j, r)
+  // is row 16 i + 4 blk + i', column 16 j + 4((blk + r) & 3) + j of the wave tile. ----
   const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + 4 * fblk + fk;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + fk + 4 * r;
+        const int n = n0 + wn * (BN / 2) + j * 16 + brot[r];
         if (m < g.M && n < g.N) {
           double* cp = C + (int64_t)m * g.ldc + n;
           double v = alpha * acc[i][j][r];
@@ -174,8 +199,16 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   int tiles = a.tiles_m * a.tiles_n;
   int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
   dim3 g(grid), blk(256);
-#define WV_LAUNCH(AK, BK, BNN) \
-  hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN>), g, blk, 0, st, a)
+  static int occ = -1;
+  if (occ < 0) {
+    const char* e = getenv("WV_GEMM_OCC");
+    occ = (e && atoi(e) == 1) ? 1 : 2;
+  }
+#define WV_LAUNCH(AK, BK, BNN)                                                  \
+  do {                                                                          \
+    if (occ == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 1>), g, blk, 0, st, a); \
+    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 2>), g, blk, 0, st, a);          \
+  } while (0)
   if (bn == 128) {
     if (a_kc && b_kc) WV_LAUNCH(true, true, 128);
     else if (a_kc && !b_kc) WV_LAUNCH(true, false, 128);

@@ -47,6 +47,18 @@ class Context:
                                                  C.byref(ms)), "wv_dbg_mfma_f64_rate")
         return tf.value, ms.value
 
+    def valu_f64_rate(self, iters=20000, waves_per_simd=2, mode=0):
+        v, m = C.c_double(), C.c_double()
+        _lib.check(self.lib.wv_dbg_valu_f64_rate(self.handle, iters, waves_per_simd, mode, C.byref(v),
+                                                 C.byref(m)), "wv_dbg_valu_f64_rate")
+        return v.value, m.value
+
+    def gemm_bench(self, M, N, K, a_kcontig=True, b_kcontig=True, bn=128, nbatch=1, iters=5):
+        tf, ms = C.c_double(), C.c_double()
+        _lib.check(self.lib.wv_dbg_gemm_bench(self.handle, M, N, K, int(a_kcontig), int(b_kcontig), bn,
+                                              nbatch, iters, C.byref(tf), C.byref(ms)), "wv_dbg_gemm_bench")
+        return tf.value, ms.value
+
     def copy_rate(self, nbytes=1 << 30, iters=10):
         g = C.c_double()
         _lib.check(self.lib.wv_dbg_copy_rate(self.handle, int(nbytes), iters, C.byref(g)), "wv_dbg_copy_rate")
