@@ -1,0 +1,189 @@
+"""bench.py - BASELINE.json metric: GP model fits/sec (N=2048, fp64, 100 L-BFGS steps).
+
+One "step" = one pass of the hot path over one batch of synthetic tasks: every rank fits
+`--tasks` (Y column) tasks of the headline workload (N=2048, D=3, kernel
+sum_d SE[d] + Periodic(SE)[d], Constant mean, GPflow default start) for exactly 100 L-BFGS-B
+iterations (maxiter=100, ftol=gtol=0) on its own GPU.  Weak scaling: per-GPU work is fixed.
+For N>1 the driver launches this with torch.distributed.run; X and Y are generated on rank 0,
+broadcast over RCCL, and the per-task score records are all-gathered after every step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant MFMA
+GEMM stage, HIP-event timed inside the timed region) and `cpu_baseline` (the NumPy/SciPy oracle
+port timed on this box's host cores, N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MATRIX_TFLOPS = 78.6  # AMD MI355X datasheet FP64 matrix; measured v_mfma_f64_4x4x4_4b_f64
+                                # back-to-back issue: 73.4 TF (tools/probe_rates.py), the local guide
+                                # lists no f64 matrix rate
+N_HEAD, D_HEAD = 2048, 3
+GEMM_STAGES = ("chol_trsm", "chol_panel_update", "chol_trailing_syrk", "trtri_tri_gemm", "trtri_diag_gemm",
+               "lauum_gemm")
+
+
+def make_inputs(P, seed=9102 + 2):
+    """U(-3,3) columns standardised with ddof=1; y_p = sum_d a sin(w x_d) + noise."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-3, 3, size=(N_HEAD, D_HEAD))
+    X = (X - X.mean(0)) / X.std(0, ddof=1)
+    a = rng.normal(size=(P, D_HEAD))
+    w = rng.uniform(0.5, 3.0, size=(P, D_HEAD))
+    Y = np.stack([sum(a[p, d] * np.sin(w[p, d] * X[:, d]) for d in range(D_HEAD))
+                  + 0.1 * rng.normal(size=N_HEAD) for p in range(P)], axis=0)  # P x N
+    return X, Y
+
+
+def headline_spec():
+    from waveome_amd import ModelSpec
+    from waveome_amd import kernels as K
+
+    kern = K.Sum([K.SquaredExponential(active_dims=[d]) for d in range(D_HEAD)]
+                 + [K.Periodic(K.SquaredExponential(active_dims=[d])) for d in range(D_HEAD)])
+    return ModelSpec(kern, D_HEAD, mean_function=K.ConstantMean())
+
+
+def cpu_baseline(X, Y, seconds_budget=20.0):
+    """Oracle port (NumPy/SciPy, LAPACK threads = host cores) on a bounded sample: SciPy L-BFGS-B on
+    task 0 for a few iterations, scaled to the 100-iteration fit of the metric."""
+    from oracle import gp_oracle as o
+
+    spec = headline_spec().to_dict()
+    u0 = o.pack_u(spec, o.theta_init(spec))
+    t0 = time.perf_counter()
+    o.objective(spec, u0, X, Y[0])
+    t_eval = time.perf_counter() - t0
+    iters = int(max(2, min(20, seconds_budget / max(t_eval * 1.1, 1e-3))))
+    t0 = time.perf_counter()
+    res = o.fit(spec, X, Y[0], maxiter=iters, ftol=0.0, gtol=0.0)
+    dt = time.perf_counter() - t0
+    fits_per_s = (res["nit"] / 100.0) / dt
+    return {"value": fits_per_s, "unit": "fits/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"task 0 of the workload, {res['nit']} L-BFGS-B iterations ({res['nfev']} value+grad "
+                      f"evaluations, {dt:.1f} s) of oracle/gp_oracle.py, scaled to 100 iterations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tasks", type=int, default=64, help="fits per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="fits in flight per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
+            sys.exit(2)
+
+    from waveome_amd import parallel
+    from waveome_amd.engine import Context, Problem, lbfgs_opts
+
+    P = args.tasks * world
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev = torch.device("cuda", local_rank)
+        X_h, Y_h = make_inputs(P) if rank == 0 else (None, None)
+        Xt = parallel.broadcast_array(X_h, 0, dev)  # RCCL broadcast of the design matrix
+        Yt = parallel.broadcast_array(Y_h, 0, dev)  # and of the outputs (P x N)
+        torch.cuda.synchronize()
+        ctx = Context(local_rank)
+        spec = headline_spec()
+        prob = Problem(ctx, None, None, spec, max_batch=args.batch, x_device_ptr=Xt.data_ptr(),
+                       y_device_ptr=Yt.data_ptr(), shape=(N_HEAD, D_HEAD, P))
+    else:
+        X_h, Y_h = make_inputs(P)
+        ctx = Context(0)
+        spec = headline_spec()
+        prob = Problem(ctx, X_h, Y_h.T, spec, max_batch=args.batch)  # inputs now resident in HBM
+
+    my_cols = parallel.shard_tasks(P, rank, world).astype(np.int32)
+    U0 = np.tile(spec.unconstrain(), (len(my_cols), 1))
+    opts = lbfgs_opts(maxiter=100, maxfun=100000, ftol=0.0, gtol=0.0)
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        res = prob.fit(my_cols, U0, opts)
+        rec = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
+        return parallel.gather_records(rec, my_cols, P, device=(dev if world > 1 else None)), res
+
+    for _ in range(args.warmup):
+        step()
+    prob.timing(True, stages=GEMM_STAGES)
+    prob.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table, res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    stages = prob.stage_times()
+    prob.timing(False)
+
+    if rank == 0:
+        fits = P * args.steps
+        nit_ok = bool(np.all(table[:, 2] == 100))
+        g = {k: stages[k] for k in GEMM_STAGES}
+        dom = max(g, key=lambda k: g[k]["ms"])
+        ach = g[dom]["flops"] / (g[dom]["ms"] * 1e-3) / 1e12 if g[dom]["ms"] > 0 else 0.0
+        tot_fl = sum(v["flops"] for v in g.values())
+        tot_ms = sum(v["ms"] for v in g.values())
+        out = {
+            "metric": "GP model fits/sec (N=2048, fp64, 100 L-BFGS steps)",
+            "value": fits / elapsed, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "headline N=2048 D=3 sum_d(SE[d]+Periodic(SE)[d]) + Constant mean, "
+                                   "100 L-BFGS-B iterations per fit (maxiter=100, ftol=gtol=0)",
+                       "fits_per_gpu_per_step": args.tasks, "fits_in_flight_per_gpu": args.batch,
+                       "parallelism": f"task-sharded x{world}", "all_fits_ran_100_iterations": nit_ok,
+                       "mean_evals_per_fit": float(table[:, 3].mean()),
+                       "evals_per_s": float(table[:, 3].sum() * args.steps / elapsed),
+                       "mean_lml": float(table[:, 1].mean())},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_f64_kernel ({dom})", "achieved": ach,
+                         "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": None,
+                         "launches": g[dom]["launches"], "avg_launch_ms": g[dom]["ms"] / max(1, g[dom]["launches"]),
+                         "all_gemm_stages_tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0,
+                         "stage_ms": {k: round(v["ms"], 3) for k, v in g.items()},
+                         "stage_tflops": {k: (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
+                                          for k, v in g.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X_h, Y_h)
+        print(json.dumps(out), flush=True)
+    prob.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

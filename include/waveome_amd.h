@@ -162,6 +162,8 @@ int32_t wv_device_count(int32_t* count_out);
 /* One context per GPU / process.  dtype: 0 = float64 (only value supported in ABI v1). */
 int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out);
 void wv_ctx_destroy(wv_ctx* ctx);
+/* Block until all work queued on this context's GPU has finished (hipDeviceSynchronize). */
+int32_t wv_ctx_synchronize(wv_ctx* ctx);
 
 /* Copies X (N x D) and Y (P x N) to HBM once, uploads the spec and sizes the
  * workspace for `max_batch` fits in flight (two N x N matrices per slot).
@@ -217,6 +219,8 @@ int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const dou
 int32_t wv_stage_times(wv_problem* prob, int32_t cap, const char** names_out, double* ms_out,
                        int64_t* launches_out, double* flops_out, double* bytes_out);
 void wv_stage_times_reset(wv_problem* prob);
+/* on = 0: off; 1: every stage; otherwise a bitmask with bit (s + 1) enabling stage s
+ * (stage order as returned by wv_stage_times). Event pairs cost ~2 us per timed launch. */
 void wv_stage_timing_enable(wv_problem* prob, int32_t on);
 
 #ifdef __cplusplus

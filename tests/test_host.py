@@ -1,0 +1,280 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, the host L-BFGS-B
+matches SciPy's, the spec helpers match the oracle, the GPSearch / full_kernel_build mirrors
+reproduce the reference's structure.  No compute call touches a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.optimize
+
+from oracle import gp_oracle as o
+from waveome_amd import ModelSpec, _lib
+from waveome_amd import kernels as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = set()
+    for hdr in ("waveome_amd.h", "waveome_amd_debug.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(wv_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes table and headers disagree"
+    assert lib.wv_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly_not_silently(lib):
+    n = C.c_int32(-1)
+    assert lib.wv_device_count(C.byref(n)) == 0
+    if n.value == 0:
+        h = C.c_void_p()
+        rc = lib.wv_ctx_create(0, 0, C.byref(h))
+        assert rc == -3 and b"no HIP device" in lib.wv_last_error()
+
+
+# ---------------------------------------------------------------- L-BFGS-B vs SciPy
+def _run_mine(lib, fun, x0, **kw):
+    op = _lib.LbfgsOpts()
+    lib.wv_lbfgs_default_opts(C.byref(op))
+    for k, v in kw.items():
+        setattr(op, k, v)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    n = len(x0)
+    h = C.c_void_p()
+    assert lib.wv_lbfgs_create(n, C.byref(op), _lib.as_dp(x0), C.byref(h)) == 0
+    evals, task = [], _lib.LB_FG
+    while task == _lib.LB_FG:
+        x = np.ctypeslib.as_array(lib.wv_lbfgs_x(h), shape=(n,)).copy()
+        f, g = fun(x)
+        evals.append((x, f))
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        task = lib.wv_lbfgs_feed(h, float(f), _lib.as_dp(g))
+    out = dict(task=task, nit=lib.wv_lbfgs_n_iter(h), nfev=lib.wv_lbfgs_n_eval(h), f=lib.wv_lbfgs_f(h),
+               x=np.ctypeslib.as_array(lib.wv_lbfgs_x(h), shape=(n,)).copy(), evals=evals)
+    lib.wv_lbfgs_destroy(h)
+    return out
+
+
+def _run_scipy(fun, x0, **opt):
+    evals = []
+
+    def f(x):
+        v, g = fun(x)
+        evals.append((x.copy(), v))
+        return v, g
+
+    res = scipy.optimize.minimize(f, x0, jac=True, method="L-BFGS-B", options=opt)
+    return res, evals
+
+
+def test_lbfgs_trajectory_matches_scipy_on_rosenbrock(lib):
+    from scipy.optimize import rosen, rosen_der
+
+    fun = lambda x: (rosen(x), rosen_der(x))
+    x0 = np.linspace(-1.2, 1.0, 10)
+    res, ev_s = _run_scipy(fun, x0, maxiter=300)
+    mine = _run_mine(lib, fun, x0, maxiter=300)
+    assert (mine["nit"], mine["nfev"]) == (res.nit, res.nfev)
+    assert mine["task"] == _lib.LB_CONV_FTOL and "REL" in res.message.upper()
+    # identical algorithm: every trial point agrees until rounding drift (two-loop vs compact form)
+    for (xa, _), (xb, _) in list(zip(mine["evals"], ev_s))[:40]:
+        np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(mine["x"], res.x, atol=1e-6)
+
+
+def test_lbfgs_matches_scipy_on_convex_problems(lib):
+    rng = np.random.default_rng(0)
+    A, b = rng.normal(size=(30, 12)), rng.normal(size=30)
+
+    def fq(x):
+        r = A @ x - b
+        return 0.5 * r @ r + 0.1 * np.sum(np.log(np.cosh(x))), A.T @ r + 0.1 * np.tanh(x)
+
+    def fexp(x):
+        e = np.exp(0.3 * (A @ x))
+        return np.sum(e) - b @ (A @ x), 0.3 * A.T @ e - A.T @ b
+
+    for fun in (fq, fexp):
+        res, ev_s = _run_scipy(fun, np.zeros(12), maxiter=500)
+        mine = _run_mine(lib, fun, np.zeros(12), maxiter=500)
+        assert (mine["nit"], mine["nfev"]) == (res.nit, res.nfev)
+        for (xa, fa), (xb, fb) in zip(mine["evals"], ev_s):
+            np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-10)
+        assert mine["f"] == pytest.approx(res.fun, rel=1e-13)
+
+
+def test_lbfgs_on_reference_known_answers(lib, golden_dir):
+    import json
+
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    for name in ("kat1", "kat2", "kat3"):
+        c = kat[name]
+        X, Y = np.array(c["X"]).reshape(-1, 1), np.array(c["Y"])
+        spec = o.make_spec(1, [[(c["kernel"], [0])]], mean=False)
+        fun = lambda u: o.objective(spec, u, X, Y)
+        u0 = o.pack_u(spec, o.theta_init(spec))
+        res, _ = _run_scipy(fun, u0, maxiter=100)
+        mine = _run_mine(lib, fun, u0, maxiter=100)
+        assert (mine["nit"], mine["nfev"]) == (res.nit, res.nfev)
+        assert mine["f"] == pytest.approx(res.fun, rel=1e-12)
+    # KAT-1's stored LML
+    assert -mine["f"] == pytest.approx(-10.689592369875864, rel=1e-10)
+
+
+def test_lbfgs_limits_and_nonfinite(lib):
+    from scipy.optimize import rosen, rosen_der
+
+    fun = lambda x: (rosen(x), rosen_der(x))
+    m = _run_mine(lib, fun, np.zeros(6), maxiter=7)
+    r, _ = _run_scipy(fun, np.zeros(6), maxiter=7)
+    assert m["task"] == _lib.LB_STOP_MAXITER and m["nit"] == 7 == r.nit and m["nfev"] == r.nfev
+    m = _run_mine(lib, fun, np.zeros(6), maxiter=10000, maxfun=20)
+    assert m["task"] == _lib.LB_STOP_MAXFUN
+    # a wall of +inf beyond |x| > 1.5: the line search must back off, not crash
+    def walled(x):
+        if np.any(np.abs(x) > 1.5):
+            return np.inf, np.zeros_like(x)
+        return rosen(x), rosen_der(x)
+    m = _run_mine(lib, walled, np.full(4, -1.2), maxiter=500)
+    assert m["task"] in (_lib.LB_CONV_FTOL, _lib.LB_CONV_GTOL) and m["f"] < 1e-6
+
+
+# ---------------------------------------------------------------- spec helpers
+def _model():
+    frozen = K.Categorical(active_dims=[3])
+    K.set_trainable(frozen.variance, False)
+    kern = K.Sum([K.Categorical(active_dims=[3]), K.SquaredExponential(active_dims=[0]),
+                  K.Periodic(K.SquaredExponential(active_dims=[1])),
+                  K.Product([frozen, K.Matern32(active_dims=[0])])])
+    ms = ModelSpec(kern, 4, mean_function=K.ConstantMean())
+    for n, p in zip(ms.param_names, ms.param_objs):
+        if "kernel" in n and "variance" in n and p.trainable:
+            p.prior = K.Horseshoe(0.5)
+    return ms
+
+
+def test_spec_transforms_and_prior_match_oracle(lib):
+    ms = _model()
+    d = ms.to_dict()
+    n = C.c_int32()
+    assert lib.wv_spec_check(C.byref(ms.to_ctypes()), C.byref(n)) == 0 and n.value == ms.n_trainable == 10
+    rng = np.random.default_rng(1)
+    u = ms.unconstrain() + rng.normal(size=ms.n_trainable)
+    th = ms.constrain(u)
+    np.testing.assert_allclose(th, o.unpack_u(d, u), rtol=1e-15)
+    np.testing.assert_allclose(ms.unconstrain(th), u, rtol=1e-12, atol=1e-12)
+    val, grad = ms.log_prior(th, grad=True)
+    assert val == pytest.approx(o.log_prior(d, th), rel=1e-14)
+    np.testing.assert_allclose(grad, o.log_prior_grad(d, th), rtol=1e-12)
+    assert th[6] == 1.0  # frozen categorical variance keeps its init
+
+
+def test_spec_rejects_malformed_input(lib):
+    ms = _model()
+    cs = ms.to_ctypes()
+    cs.noise_param = 99
+    assert lib.wv_spec_check(C.byref(cs), None) == -2 and b"noise_param" in lib.wv_last_error()
+    cs = ms.to_ctypes()
+    cs.factors[0].dim_mask = 1 << 9  # column 9 of a 4-column X
+    assert lib.wv_spec_check(C.byref(cs), None) == -2
+    with pytest.raises(ValueError):
+        ModelSpec(K.SquaredExponential(active_dims=[7]), 3)
+    with pytest.raises(NotImplementedError):
+        K.Periodic(K.Matern32())
+
+
+def test_product_of_sums_is_distributed():
+    a, b, c = K.SquaredExponential(active_dims=[0]), K.Matern12(active_dims=[1]), K.Lin(active_dims=[2])
+    ms = ModelSpec((a + b) * c, 3)
+    assert [[f["type"] for f in t] for t in ms.terms] == [["se", "lin"], ["m12", "lin"]]
+    assert ms.terms[0][1]["p"] == ms.terms[1][1]["p"]  # the shared Lin variance is ONE parameter
+
+
+# ---------------------------------------------------------------- reference-API mirrors
+def _iris():
+    from sklearn.datasets import load_iris
+
+    ir = load_iris(as_frame=True).frame
+    ir.columns = ["sepal_length", "sepal_width", "petal_length", "petal_width", "species"]
+    ir["species"] = ir["species"].map({0: "setosa", 1: "versicolor", 2: "virginica"})
+    return ir
+
+
+def test_gpsearch_constructor_preprocessing():
+    from waveome_amd.model_search import GPSearch
+
+    ir = _iris()
+    gps = GPSearch(X=ir[["sepal_length", "sepal_width", "species"]], Y=ir[["petal_length", "petal_width"]],
+                   categorical_vars=["species"])
+    assert gps.cat_idx == [2] and gps.cont_idx == [0, 1] and gps.unit_idx is None
+    assert gps.out_names == ["petal_length", "petal_width"]
+    x0 = ir["sepal_length"].to_numpy()
+    np.testing.assert_allclose(gps.X["sepal_length"], (x0 - x0.mean()) / x0.std(ddof=1), rtol=1e-14)
+    assert set(gps.X["species"].unique()) == {0.0, 1.0, 2.0}
+    with pytest.raises(TypeError):
+        GPSearch(X=ir[["sepal_length"]].to_numpy(), Y=ir[["petal_length"]])
+    bad = ir[["sepal_length", "sepal_width"]].copy()
+    bad.iloc[3, 0] = np.nan
+    with pytest.raises(AssertionError):
+        GPSearch(X=bad, Y=ir[["petal_length"]])
+    g2 = GPSearch(X=ir[["sepal_length", "sepal_width"]], Y=ir[["petal_length"]], Y_transform="standardize")
+    assert abs(g2.Y["petal_length"].std(ddof=1) - 1) < 1e-12
+
+
+def test_full_kernel_build_structure_and_order():
+    from waveome_amd.regularization import full_kernel_build
+
+    names = ["id", "grp", "t", "dose"]
+    kern, labels = full_kernel_build(cat_vars=[0, 1], num_vars=[2, 3], unit_idx=0, var_names=names,
+                                     return_sum=True, kerns=[K.SquaredExponential(), K.Periodic()],
+                                     unit_numeric_interactions=True, second_order_numeric=True)
+    # regularization.py:57-178 order: unit, cats, numeric x kerns, unit x numeric, cat x numeric, numeric x numeric
+    assert labels[:2] == ["categorical[id]", "categorical[grp]"]
+    assert labels[2:6] == ["squared_exponential[t]", "periodic[t]", "squared_exponential[dose]", "periodic[dose]"]
+    assert labels[6] == "categorical[id]*squared_exponential[t]"
+    assert labels[10] == "categorical[grp]*squared_exponential[t]"
+    assert len(labels) == 2 + 4 + 4 + 4 + 12 == len(kern.kernels)  # :152-178 double counts k1*k2 / k2*k1 on one column
+    prod = kern.kernels[6]
+    assert prod.name == "product" and prod.kernels[0].variance.trainable is False  # :109, :132
+    assert prod.kernels[1].active_dims == [2]
+    # C3 of BASELINE.json: 1 categorical + 4 numeric, kerns = [SE, Periodic] -> 17 terms, 41 kernel params
+    k3 = full_kernel_build(cat_vars=[4], num_vars=[0, 1, 2, 3], return_sum=True,
+                           kerns=[K.SquaredExponential(), K.Periodic()])
+    ms = ModelSpec(k3, 5, mean_function=K.ConstantMean())
+    assert len(ms.terms) == 17
+    assert sum(1 for n, p in zip(ms.param_names, ms.param_objs) if n.startswith("kernel") and p.trainable) == 41
+
+
+def test_pruning_rules_and_bic():
+    from waveome_amd.model_classes import PSVGP
+    from waveome_amd.utilities import calc_bic, find_variance_components, print_kernel_names
+
+    X = np.random.default_rng(0).normal(size=(20, 2))
+    kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.SquaredExponential(active_dims=[1]),
+                  K.Product([K.Categorical(active_dims=[0]), K.Matern12(active_dims=[1])])])
+    kern.kernels[0].variance.assign(0.05)  # below var_cutoff
+    kern.kernels[1].lengthscales.assign(1e3)  # >= 3 ptp -> dropped
+    m = PSVGP.__new__(PSVGP)
+    m.kernel, m.data = kern, (X, X[:, :1])
+    np.testing.assert_allclose(find_variance_components(kern, sum_reduce=False).ravel(), [0.05, 1.0, 1.0])
+    PSVGP.cut_kernel_components(m)
+    assert print_kernel_names(m.kernel, with_idx=True) == "categorical[0]*matern12[1]"
+    kern2 = K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])])
+    kern2.kernels[0].variance.assign(1e-3)
+    kern2.kernels[1].variance.assign(1e-3)
+    m.kernel = kern2
+    PSVGP.cut_kernel_components(m)
+    assert m.kernel.name == "constant"  # model_classes.py:1063
+    assert calc_bic(loglik=-10.0, n=100, k=3) == 26.0

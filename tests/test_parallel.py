@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a task list, broadcast inputs and gather
+fixed-width records; the result must be bit-identical to the single-process run."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["WV_ROOT"])
+import torch.distributed as dist
+from waveome_amd import parallel
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = parallel.dist_info()
+rng = np.random.default_rng(5)
+X = rng.normal(size=(40, 3)) if rank == 0 else None
+Y = rng.normal(size=(11, 40)) if rank == 0 else None
+Xt = parallel.broadcast_array(X).numpy()
+Yt = parallel.broadcast_array(Y).numpy()
+costs = np.arange(11)[::-1] % 4
+def fn(ids):
+    return np.column_stack([[float(np.dot(Yt[i], Xt[:, 0])) for i in ids], [Yt[i].sum() * (i + 1) for i in ids], ids.astype(float)])
+out = parallel.sharded_map(11, fn, costs=costs)
+mine = parallel.shard_tasks(11, rank, world, costs)
+np.save(os.environ["WV_OUT"] + f".{rank}.npy", out)
+np.save(os.environ["WV_OUT"] + f".ids{rank}.npy", mine)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_tasks_is_a_balanced_partition():
+    from waveome_amd.parallel import shard_tasks
+
+    costs = np.array([5, 1, 9, 9, 2, 7, 3, 3, 8, 1, 6, 4, 2], dtype=float)
+    shards = [shard_tasks(len(costs), r, 4, costs) for r in range(4)]
+    assert sorted(np.concatenate(shards).tolist()) == list(range(len(costs)))
+    loads = [costs[s].sum() for s in shards]
+    assert max(loads) - min(loads) <= costs.max()
+    assert shard_tasks(5, 0, 1).tolist() == [0, 1, 2, 3, 4]
+
+
+def test_world_size_two_gloo_matches_single_process(tmp_path):
+    port = _free_port()
+    out = str(tmp_path / "rec")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WV_ROOT=ROOT, WV_OUT=out, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        log, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, log.decode()[-2000:]
+    r0, r1 = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    np.testing.assert_array_equal(r0, r1)  # every rank holds the full gathered table
+    rng = np.random.default_rng(5)
+    X, Y = rng.normal(size=(40, 3)), rng.normal(size=(11, 40))
+    ids = np.arange(11)
+    ref = np.column_stack([[float(np.dot(Y[i], X[:, 0])) for i in ids], [Y[i].sum() * (i + 1) for i in ids], ids.astype(float)])
+    np.testing.assert_array_equal(r0, ref)  # bit-identical to the 1-process result
+    i0, i1 = np.load(out + ".ids0.npy"), np.load(out + ".ids1.npy")
+    assert sorted(np.concatenate([i0, i1]).tolist()) == list(range(11)) and abs(len(i0) - len(i1)) <= 1

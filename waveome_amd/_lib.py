@@ -70,6 +70,7 @@ SIGNATURES = {
     "wv_device_count": (C.c_int32, [_ip]),
     "wv_ctx_create": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "wv_ctx_destroy": (None, [_vp]),
+    "wv_ctx_synchronize": (C.c_int32, [_vp]),
     "wv_problem_create": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32,
                                       C.POINTER(KernelSpec), C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(_vp)]),

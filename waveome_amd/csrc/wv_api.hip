@@ -19,7 +19,8 @@ const char* const kStageNames[ST_COUNT] = {
 
 // ---------------- stage timer ----------------
 void StageTimer::begin(hipStream_t s, int stage) {
-  if (!enabled) return;
+  cur = enabled && (mask >> stage & 1u);
+  if (!cur) return;
   Rec r;
   auto get = [&]() {
     hipEvent_t e;
@@ -38,7 +39,8 @@ void StageTimer::begin(hipStream_t s, int stage) {
   pending.push_back(r);
 }
 void StageTimer::end(hipStream_t s) {
-  if (!enabled || pending.empty()) return;
+  if (!cur || pending.empty()) return;
+  cur = false;
   hipEventRecord(pending.back().b, s);
 }
 void StageTimer::collect() {
@@ -243,6 +245,13 @@ int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out) {
 }
 
 void wv_ctx_destroy(wv_ctx* ctx) { delete ctx; }
+
+int32_t wv_ctx_synchronize(wv_ctx* ctx) {
+  if (!ctx) return WV_E_BADARG;
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  WV_HIP_TRY(hipDeviceSynchronize());
+  return WV_OK;
+}
 
 void wv_problem_destroy(wv_problem* h) {
   if (!h) return;
@@ -604,6 +613,7 @@ void wv_stage_timing_enable(wv_problem* h, int32_t on) {
   if (h) {
     h->p.timer.collect();
     h->p.timer.enabled = on != 0;
+    h->p.timer.mask = (on == 0 || on == 1) ? 0xffffffffu : ((uint32_t)on >> 1);
   }
 }
 

@@ -81,6 +81,8 @@ extern const char* const kStageNames[ST_COUNT];
 
 struct StageTimer {
   bool enabled = false;
+  uint32_t mask = 0xffffffffu;  // bit s: stage s is timed
+  bool cur = false;
   struct Rec { hipEvent_t a, b; int stage; };
   std::vector<Rec> pending;
   std::vector<hipEvent_t> pool;
@@ -92,7 +94,7 @@ struct StageTimer {
   void end(hipStream_t s);
   void collect();
   void reset();
-  void work(int stage, double fl, double by) { if (enabled) { flops[stage] += fl; bytes[stage] += by; } }
+  void work(int stage, double fl, double by) { if (enabled && (mask >> stage & 1u)) { flops[stage] += fl; bytes[stage] += by; } }
   ~StageTimer();
 };
 

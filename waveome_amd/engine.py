@@ -40,6 +40,9 @@ class Context:
         except Exception:
             pass
 
+    def synchronize(self):
+        _lib.check(self.lib.wv_ctx_synchronize(self.handle), "wv_ctx_synchronize")
+
     # ---- bring-up probes (include/waveome_amd_debug.h) ----
     def mfma_f64_rate(self, iters=20000, waves_per_simd=1):
         tf, ms = C.c_double(), C.c_double()
@@ -163,8 +166,19 @@ class Problem:
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
 
     # ---- timing ----
-    def timing(self, on: bool):
-        self.lib.wv_stage_timing_enable(self.handle, 1 if on else 0)
+    STAGES = ("gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
+              "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce")
+
+    def timing(self, on, stages=None):
+        """on=False: off; on=True: all stages, or only the named `stages`."""
+        code = 0
+        if on:
+            code = 1
+            if stages:
+                code = 0
+                for s in stages:
+                    code |= 1 << (self.STAGES.index(s) + 1)
+        self.lib.wv_stage_timing_enable(self.handle, code)
 
     def timing_reset(self):
         self.lib.wv_stage_times_reset(self.handle)

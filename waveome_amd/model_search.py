@@ -1,0 +1,184 @@
+"""GPSearch - the caller-facing entry of the path: constructor preprocessing and
+`penalized_optimization()` (reference waveome/model_search.py:47-517), GPflow/Ray-free.
+
+What is kept verbatim: argument names and defaults, categorical factorisation, float casts, NaN
+asserts, ddof=1 standardisation, `self.models[out_name]`, `self.model_selection_type`,
+`self.run_parameters`, the progress prints.  What is replaced: the per-output Ray task
+(:250-393) becomes one batched GPU fit over all outputs (sharded over ranks when
+torch.distributed is initialised); `time.sleep(10)` and `rm -rf /tmp/ray` are not reproduced."""
+from __future__ import annotations
+
+import copy
+import time
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from . import kernels as K
+from . import parallel
+from .engine import Problem, lbfgs_opts
+from .model_classes import PSVGP, default_context
+from .regularization import full_kernel_build
+from .spec import ModelSpec
+
+
+class GPSearch:
+    """Gaussian process model search class (constructor: model_search.py:73-191)."""
+
+    def __init__(self, X, Y, unit_col=None, standardize_X=True, Y_transform=None, categorical_vars=[],
+                 outcome_likelihood="gaussian"):
+        if not isinstance(X, pd.DataFrame):
+            raise TypeError("X is not a Pandas DataFrame")
+        if not isinstance(Y, pd.DataFrame):
+            raise TypeError("Y is not a Pandas DataFrame")
+        X = X.copy()
+        categorical_vars = list(categorical_vars)  # the reference mutates its default argument
+        if unit_col is not None and unit_col not in categorical_vars:
+            categorical_vars += [unit_col]
+        self.categorical_dict = {}
+        for c in categorical_vars:
+            if X[c].dtype in ["object", "string"] or str(X[c].dtype) in ("object", "string", "category", "str"):
+                print(f"Converting {c} to numeric")
+                factor_out = pd.factorize(X[c])
+                self.categorical_dict[c] = factor_out
+                X[c] = factor_out[0].astype(float)
+        try:
+            X = X.astype(float)
+        except Exception:
+            raise TypeError("X columns must all be float type. Perhaps use pandas.factorize() and"
+                            " pandas.DataFrame.astype().")
+        try:
+            Y = Y.astype(float)
+        except Exception:
+            raise TypeError("Y columns must all be float type. Perhaps use pandas.factorize() and"
+                            " pandas.DataFrame.astype().")
+        assert X.isna().sum().sum() == 0, "NAs in X, waveome cannot currently handle missing values!"
+        assert Y.isna().sum().sum() == 0, "NAs in Y, waveome cannot currently handle missing values!"
+        self.X = X.copy()
+        self.Y = Y.copy()
+        self.feat_names = X.columns.tolist()
+        self.out_names = Y.columns.tolist()
+        self.cat_idx = [self.feat_names.index(x) for x in categorical_vars]
+        self.unit_idx = self.feat_names.index(unit_col) if unit_col is not None else None
+        self.likelihood = outcome_likelihood
+        self.cont_idx = np.where(~np.isin(np.arange(X.shape[1]), self.cat_idx))[0].tolist()
+        if standardize_X:
+            self.X_means = self.X.iloc[:, self.cont_idx].mean(axis=0)
+            self.X_stds = self.X.iloc[:, self.cont_idx].std(axis=0)  # pandas: ddof = 1
+            self.X_original = self.X.copy()
+            for c in self.cont_idx:
+                name = self.feat_names[c]
+                self.X[name] = (self.X[name] - self.X_means[name]) / self.X_stds[name]
+        if Y_transform == "standardize":
+            if self.likelihood != "gaussian":
+                warnings.warn("Standardizing Y without a gaussian likelihood is not advised!")
+            self.Y_means = self.Y.mean(axis=0)
+            self.Y_stds = self.Y.std(axis=0)
+            self.Y_original = self.Y.copy()
+            self.Y = (self.Y - self.Y_means) / self.Y_stds
+        elif Y_transform == "scale":
+            self.Y_stds = self.Y.std(axis=0)
+            self.Y_original = self.Y.copy()
+            self.Y = self.Y / self.Y_stds
+
+    # ------------------------------------------------------------------------------------------
+    def penalized_optimization(self, full_kernel=None, num_jobs=-1, verbose=False, mean_function=None,
+                               kernel_options={"second_order_numeric": False,
+                                               "categorical_numeric_interactions": True,
+                                               "unit_numeric_interactions": False, "kerns": None},
+                               penalization_factor=1.0, num_factor_iter=5, num_restart=0, sparse_options={},
+                               variational_options={}, optimization_options={"optimizer": "scipy"},
+                               random_seed=None, ray_dashboard=False, ray_logging=False, max_batch=None,
+                               context=None):
+        """Fit the saturated penalised model to every output column (model_search.py:197-517).
+
+        Extra keyword arguments (not in the reference): `max_batch` (fits in flight per GPU) and
+        `context`.  `num_jobs`, `ray_dashboard`, `ray_logging` are accepted and ignored."""
+        self.model_selection_type = "penalized"
+        if not hasattr(self, "run_parameters"):
+            self.run_parameters = {}
+        args = dict(locals())
+        del args["self"]
+        self.run_parameters["penalized_optimization"] = args
+        if self.likelihood != "gaussian":
+            raise NotImplementedError("only outcome_likelihood='gaussian' is implemented on the GPU path")
+        if optimization_options.get("optimizer", "scipy") != "scipy":
+            raise NotImplementedError("only optimization_options={'optimizer': 'scipy'} is implemented")
+        if penalization_factor is None:
+            raise NotImplementedError("penalization_factor=None (iterated analytic factor) is not implemented yet")
+        if sparse_options:
+            warnings.warn("sparse_options are ignored: the GPU path is the exact GP (all N points)")
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        if mean_function is None:
+            mean_function = K.ConstantMean()
+        if full_kernel is None:
+            ko = dict(kernel_options)
+            if ko.get("kerns") is None:
+                ko["kerns"] = [K.SquaredExponential()]
+            full_kernel, _ = full_kernel_build(cat_vars=self.cat_idx, num_vars=self.cont_idx,
+                                               unit_idx=self.unit_idx, var_names=self.feat_names,
+                                               return_sum=True, **ko)
+        else:
+            full_kernel = copy.deepcopy(full_kernel)
+        variational_options = dict(variational_options, likelihood=self.likelihood)
+
+        Xn = self.X.to_numpy(dtype=np.float64)
+        Yn = self.Y.to_numpy(dtype=np.float64)
+        P = Yn.shape[1]
+        # template model: structure, defaults and priors shared by every output
+        template = PSVGP(Xn, Yn[:, :1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
+                         penalized_options={"penalization_factor": penalization_factor},
+                         variational_options=variational_options, context=context)
+        spec = template._spec()
+        u0 = spec.unconstrain()
+        n_starts = max(1, int(num_restart))
+        rng = np.random.RandomState(random_seed)
+        starts = np.tile(u0, (P * n_starts, 1))
+        if num_restart > 0:  # model_classes.py:181-234: unconstrained values ~ N(0, 1)
+            starts = rng.normal(loc=0.0, scale=1.0, size=starts.shape)
+        cols = np.repeat(np.arange(P, dtype=np.int32), n_starts)
+
+        print(f"Building {len(self.out_names)} models...")
+        start_time = time.time()
+        ctx = context or default_context()
+        rank, world = parallel.dist_info()
+        nt = spec.n_trainable
+        opts = lbfgs_opts(maxiter=optimization_options.get("num_opt_iter", 50000))
+
+        def fit_shard(ids):
+            mb = max_batch or min(len(ids), _default_batch(len(Xn)))
+            prob = Problem(ctx, Xn, Yn, spec, max_batch=max(1, mb))
+            res = prob.fit(cols[ids], starts[ids], opts)
+            prob.close()
+            return np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"], res["u"]])
+
+        rec = parallel.sharded_map(len(cols), fit_shard) if world > 1 else fit_shard(np.arange(len(cols)))
+        self.fit_records = rec
+        self.models = {}
+        for p, feat in enumerate(self.out_names):
+            block = rec[p * n_starts:(p + 1) * n_starts]
+            best = block[np.argmin(block[:, 0])]  # lowest training loss over restarts
+            mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
+                        penalized_options={"penalization_factor": penalization_factor},
+                        variational_options=variational_options, context=context)
+            mspec = mod._spec()
+            mspec.assign_theta(mspec.constrain(best[5:5 + nt]))
+            mod.fit_result = {"loss": best[0], "lml": best[1], "nit": int(best[2]), "nfev": int(best[3]),
+                              "status": int(best[4])}
+            mod.optimizer = "scipy"
+            mod.cut_kernel_components(data=(Xn, Yn[:, p:p + 1]))
+            mod.update_kernel_name()
+            self.models[feat] = mod
+        c = len(self.out_names)
+        elapsed_time = np.round((time.time() - start_time) / 60, 1)
+        print(f"Finished {c} models (100%),", f"elapsed time: {elapsed_time} minutes")
+        return None
+
+
+def _default_batch(n: int) -> int:
+    """Fits in flight per GPU: two N x N float64 matrices per slot, capped at ~64 GiB of HBM."""
+    npad = (n + 63) // 64 * 64
+    per_slot = 2 * npad * npad * 8 + npad * 64 * 8
+    return int(max(2, min(256, (64 << 30) // per_slot)))
