@@ -136,8 +136,13 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
   WV_HIP_TRY(hipMemcpyAsync(p.dcol + g.slot0, g.h_col, sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
   launch_resid(p, st, g.slot0, nb);
   launch_gram(p, st, g.slot0, nb, 0);
-  cholesky(p, st, g.slot0, nb);
-  trtri(p, st, g.slot0, nb);
+  static const bool old_sched = std::getenv("WV_SCHED_OLD") != nullptr;
+  if (old_sched) {
+    cholesky(p, st, g.slot0, nb);
+    trtri(p, st, g.slot0, nb);
+  } else {
+    factor_inverse(p, st, g.slot0, nb);
+  }
   launch_solve(p, st, g.slot0, nb, with_grad);
   if (with_grad) {
     lauum(p, st, g.slot0, nb);
@@ -325,7 +330,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
             alloc((void**)&p.dspec, sizeof(DevSpec)) &&
             alloc((void**)&p.Kbuf, sizeof(double) * mat * max_batch) &&
             alloc((void**)&p.Mbuf, sizeof(double) * mat * max_batch) &&
-            alloc((void**)&p.Pbuf, sizeof(double) * Np * NB * max_batch) &&
+            alloc((void**)&p.Pbuf, sizeof(double) * p.pbuf_elems() * max_batch) &&
             alloc((void**)&p.dtheta, sizeof(double) * np * max_batch) &&
             alloc((void**)&p.dr, sizeof(double) * Np * max_batch) &&
             alloc((void**)&p.dz, sizeof(double) * Np * max_batch) &&

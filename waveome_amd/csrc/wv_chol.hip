@@ -21,6 +21,34 @@ constexpr int DS = NB + 1;  // LDS row stride of the 64x64 diagonal block
 // A non-positive / NaN pivot sets status[slot] = 1 and is replaced by 1 so the pipeline
 // keeps running on finite numbers (the host reports +inf for that task).
 // ---------------------------------------------------------------------------------------
+// Triangular-inverse combine step of size H inside the 64x64 block: for every 2H diagonal block
+// X21 = -X22 (L21 X11), all operands in LDS.
+template <int H>
+__device__ inline void inv_level(const double* __restrict__ L, double* __restrict__ X,
+                                 double* __restrict__ T, int tid) {
+  constexpr int NPAIR = NB / (2 * H);
+  constexpr int PER = H * H;
+  for (int q = tid; q < NPAIR * PER; q += 256) {
+    const int blk = q / PER, e = q % PER, i = e / H, c = e % H, o = blk * 2 * H;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = c; k < H; ++k) s += L[(o + H + i) * DS + o + k] * X[(o + k) * DS + o + c];
+    T[(o + H + i) * DS + o + c] = s;
+  }
+  __syncthreads();
+  for (int q = tid; q < NPAIR * PER; q += 256) {
+    const int blk = q / PER, e = q % PER, i = e / H, c = e % H, o = blk * 2 * H;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k <= i; ++k) s += X[(o + H + i) * DS + o + H + k] * T[(o + H + k) * DS + o + c];
+    X[(o + H + i) * DS + o + c] = -s;
+  }
+  __syncthreads();
+}
+
+// Register-tiled right-looking Cholesky of the 64x64 block: thread (ty, tx) of a 16 x 16 grid owns
+// rows 4 ty.., columns 4 tx.. in registers; per column one LDS broadcast of the pivot column and
+// ONE barrier (the column buffer is double-buffered).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Kall,
                                                          double* __restrict__ Mall,
                                                          double* __restrict__ logdet,
@@ -29,41 +57,79 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
   __shared__ double L[NB * DS];
   __shared__ double X[NB * DS];
   __shared__ double T[NB * DS];
+  __shared__ double colbuf[2][NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
   double* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
   double* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   if (tid == 0) bad = 0;
-  for (int q = tid; q < NB * NB; q += 256) {
-    int i = q >> 6, j = q & 63;
-    L[i * DS + j] = (j <= i) ? K[(int64_t)i * Npad + j] : 0.0;
-    X[i * DS + j] = 0.0;
+  double a[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double* src = K + (int64_t)(4 * ty + r) * Npad + 4 * tx;
+    double2 v01 = *reinterpret_cast<const double2*>(src);
+    double2 v23 = *reinterpret_cast<const double2*>(src + 2);
+    a[r][0] = v01.x; a[r][1] = v01.y; a[r][2] = v23.x; a[r][3] = v23.y;
   }
-  __syncthreads();
-  // unblocked right-looking Cholesky, two barriers per column
-  for (int j = 0; j < NB; ++j) {
-    double piv = L[j * DS + j];
-    bool ok = piv > 0.0;  // false for NaN too
-    if (!ok) piv = 1.0;
-    const double root = sqrt(piv), inv = 1.0 / root;
-    if (tid == 0 && !ok) bad = 1;
-    if (tid > j && tid < NB) L[tid * DS + j] *= inv;  // L[j][j] itself is rewritten below
-    __syncthreads();
-    // trailing update: (i, k) with j < k <= i < 64 (reads column j below the diagonal only)
-    const int rem = NB - 1 - j;
-    for (int q = tid; q < rem * rem; q += 256) {
-      int i = j + 1 + q / rem, k = j + 1 + q % rem;
-      if (k <= i) L[i * DS + k] -= L[i * DS + j] * L[k * DS + j];
+  for (int q = tid; q < NB * DS; q += 256) X[q] = 0.0;
+  bool anybad = false;
+  for (int jb = 0; jb < 16; ++jb) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * jb + jj;
+      double* cb = colbuf[j & 1];
+      if (tx == jb && ty >= jb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cb[4 * ty + r] = a[r][jj];
+      }
+      __syncthreads();
+      double piv = cb[j];
+      const bool ok = piv > 0.0;  // false for NaN as well
+      if (!ok) { piv = 1.0; anybad = true; }
+      const double inv = rsqrt(piv);
+      if (ty >= tx && tx >= jb) {
+        double lr[4], lc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lr[r] = cb[4 * ty + r] * inv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lc[c] = cb[4 * tx + c] * inv;
+        if (tx == jb) {
+          // finalise column j (rows > j; the diagonal becomes piv * inv = sqrt(piv))
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r][jj] = (ty == jb && r == jj) ? piv * inv : lr[r];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c > jj) a[r][c] -= lr[r] * lc[c];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[r][c] -= lr[r] * lc[c];
+        }
+      }
     }
-    if (tid == 255) L[j * DS + j] = root;
-    __syncthreads();
   }
-  // write L back, accumulate the log-determinant partial
-  for (int q = tid; q < NB * NB; q += 256) {
-    int i = q >> 6, j = q & 63;
-    K[(int64_t)i * Npad + j] = L[i * DS + j];
+  // L to LDS (upper part zeroed) and back to HBM
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 4 * ty + r, jc = 4 * tx + c;
+      const double v = (jc <= i) ? a[r][c] : 0.0;
+      a[r][c] = v;
+      L[i * DS + jc] = v;
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double* dst = K + (int64_t)(4 * ty + r) * Npad + 4 * tx;
+    *reinterpret_cast<double2*>(dst) = make_double2(a[r][0], a[r][1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(a[r][2], a[r][3]);
   }
+  if (anybad && tid == 0) bad = 1;
+  __syncthreads();
   if (tid < 64) {
     double v = log(L[tid * DS + tid]);
 #pragma unroll
@@ -74,8 +140,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
     }
   }
   // ---- inverse of the lower-triangular block by recursive doubling ----
-  // level 0: four 16x16 diagonal blocks, one thread per column
-  if (tid < 64) {
+  if (tid < 64) {  // level 0: four 16x16 diagonal blocks, one thread per column
     const int blk = tid >> 4, c = tid & 15, o = blk * 16;
     X[(o + c) * DS + o + c] = 1.0 / L[(o + c) * DS + o + c];
     for (int i = c + 1; i < 16; ++i) {
@@ -85,28 +150,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
     }
   }
   __syncthreads();
-  // level 1 (h = 16) and level 2 (h = 32): X21 = -X22 (L21 X11)
-  for (int h = 16; h <= 32; h <<= 1) {
-    const int nb2 = NB / (2 * h);  // number of 2h blocks
-    const int per = h * h;         // outputs per block
-    for (int q = tid; q < nb2 * per; q += 256) {
-      int blk = q / per, e = q % per, i = e / h, c = e % h, o = blk * 2 * h;
-      double s = 0.0;
-      for (int k = 0; k < h; ++k) s += L[(o + h + i) * DS + o + k] * X[(o + k) * DS + o + c];
-      T[(o + h + i) * DS + o + c] = s;
-    }
-    __syncthreads();
-    for (int q = tid; q < nb2 * per; q += 256) {
-      int blk = q / per, e = q % per, i = e / h, c = e % h, o = blk * 2 * h;
-      double s = 0.0;
-      for (int k = 0; k <= i; ++k) s += X[(o + h + i) * DS + o + h + k] * T[(o + h + k) * DS + o + c];
-      X[(o + h + i) * DS + o + c] = -s;
-    }
-    __syncthreads();
-  }
-  for (int q = tid; q < NB * NB; q += 256) {
-    int i = q >> 6, j = q & 63;
-    M[(int64_t)i * Npad + j] = X[i * DS + j];
+  inv_level<16>(L, X, T, tid);
+  inv_level<32>(L, X, T, tid);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * ty + r;
+    double* dst = M + (int64_t)i * Npad + 4 * tx;
+    *reinterpret_cast<double2*>(dst) = make_double2(X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]);
   }
 }
 
@@ -320,7 +371,7 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
   const int64_t Np = p.Npad, mat = Np * Np;
   double* K0 = p.Kbuf + (int64_t)slot0 * mat;
   double* M0 = p.Mbuf + (int64_t)slot0 * mat;
-  double* P0 = p.Pbuf + (int64_t)slot0 * Np * NB;
+  double* P0 = p.Pbuf + (int64_t)slot0 * p.pbuf_elems();
   for (int64_t j0 = Np - 2 * NB; j0 >= 0; j0 -= NB) {
     const int64_t r0 = j0 + NB, rem = Np - r0;
     {  // P = M22 * L21   (NN; M22 lower triangular -> K range ends at the tile's last row)
@@ -328,8 +379,8 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
       a.A = M0 + r0 * Np + r0;
       a.B = K0 + r0 * Np + j0;  // L21 stored [k][n]
       a.C = P0;
-      a.sC = Np * NB; a.ldc = NB;
-      a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = (int)rem; a.kmode = 1; a.koff = 0;
+      a.sC = p.pbuf_elems(); a.ldc = NB;
+      a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = (int)rem; a.khi_mode = 1; a.koff = 0;
       p.timer.begin(st, ST_TRTRI_A);
       launch_gemm(st, a, true, false, 64);
       p.timer.end(st);
@@ -337,7 +388,7 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
     }
     {  // M21 = -P * M_jj   (NN, K = 64)
       GemmArgs a = base_args(p, slot0, nb);
-      a.A = P0; a.sA = Np * NB; a.lda = NB;
+      a.A = P0; a.sA = p.pbuf_elems(); a.lda = NB;
       a.B = M0 + j0 * Np + j0;  // M_jj stored [k][n]
       a.C = M0 + r0 * Np + j0;
       a.M = (int)rem; a.N = NB; a.kb = 0; a.ke = NB; a.alpha = -1.0;
@@ -349,13 +400,87 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// factor_inverse: recursive K_y = L L' together with M = L^-1, every O(n^3) piece a square-ish
+// GEMM.  Node (o, n) splits n = h1 + h2 (multiples of 64):
+//   node(o, h1)                       -> L11 (diag blocks), M11
+//   S   = A21 M11'                    L21, kept in scratch S (contraction k < column + 1)
+//   A22 -= S S'                       Schur complement, lower tiles
+//   T   = S M11                       stored over the dead A21 block (contraction k >= column)
+//   node(o + h1, h2)                  -> M22
+//   M21 = -M22 T                      (contraction k <= row)
+// L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
+// ---------------------------------------------------------------------------------------
+static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
+  if (n == NB) {
+    launch_potrf_diag(p, st, slot0, nb, (int)o);
+    return;
+  }
+  const int64_t Np = p.Npad, mat = Np * Np;
+  const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
+  double* K0 = p.Kbuf + (int64_t)slot0 * mat;
+  double* M0 = p.Mbuf + (int64_t)slot0 * mat;
+  double* S0 = p.Pbuf + (int64_t)slot0 * p.pbuf_elems();
+  const int64_t sS = p.pbuf_elems();
+  fi_node(p, st, slot0, nb, o, h1);
+  {  // S = A21 * M11'
+    GemmArgs a = base_args(p, slot0, nb);
+    a.A = K0 + (o + h1) * Np + o;
+    a.B = M0 + o * Np + o;  // B(n, k) = M11[n][k]
+    a.C = S0; a.sC = sS; a.ldc = (int)h1;
+    a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
+    p.timer.begin(st, ST_CHOL_TRSM);
+    launch_gemm(st, a, true, true, h1 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
+  }
+  {  // A22 -= S S'
+    GemmArgs a = base_args(p, slot0, nb);
+    a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h1;
+    a.C = K0 + (o + h1) * Np + (o + h1);
+    a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
+    a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
+    p.timer.begin(st, ST_CHOL_TRAIL);
+    launch_gemm(st, a, true, true, h2 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
+  }
+  {  // T = S * M11 over the dead A21 block
+    GemmArgs a = base_args(p, slot0, nb);
+    a.A = S0; a.sA = sS; a.lda = (int)h1;
+    a.B = M0 + o * Np + o;  // B(n, k) = M11[k][n]
+    a.C = K0 + (o + h1) * Np + o;
+    a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.klo_mode = 2;
+    p.timer.begin(st, ST_TRTRI_A);
+    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
+  }
+  fi_node(p, st, slot0, nb, o + h1, h2);
+  {  // M21 = -M22 * T
+    GemmArgs a = base_args(p, slot0, nb);
+    a.A = M0 + (o + h1) * Np + (o + h1);
+    a.B = K0 + (o + h1) * Np + o;  // B(n, k) = T[k][n]
+    a.C = M0 + (o + h1) * Np + o;
+    a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h2; a.khi_mode = 1; a.alpha = -1.0;
+    p.timer.begin(st, ST_TRTRI_B);
+    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_TRTRI_B, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
+  }
+}
+
+void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb) {
+  fi_node(p, st, slot0, nb, 0, p.Npad);
+}
+
 void lauum(Problem& p, hipStream_t st, int slot0, int nb) {
   const int64_t Np = p.Npad, mat = Np * Np;
   GemmArgs a = base_args(p, slot0, nb);
   a.A = p.Mbuf + (int64_t)slot0 * mat;  // A(m, l) = M[l][m]
   a.B = p.Mbuf + (int64_t)slot0 * mat;  // B(n, l) = M[l][n]
   a.C = p.Kbuf + (int64_t)slot0 * mat;
-  a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.kmode = 2; a.koff = 0;
+  a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0;
   p.timer.begin(st, ST_LAUUM);
   launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);

@@ -135,6 +135,10 @@ int32_t wv_dbg_gemm(wv_ctx* ctx, const double* A, const double* B, double* C, in
 
 int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_kc, int32_t b_kc,
                           int32_t bn, int32_t nbatch, int32_t iters, double* tflops_out, double* ms_out) {
+  // bn encodes a structure mode in its upper bits: bn + 1000*mode; mode 1 = LAUUM-like (lower tiles,
+  // contraction from the tile row), 2 = SYRK-like (lower tiles, beta = 1), 3 = trimmed k < n0 + BN
+  const int mode = bn / 1000;
+  bn = bn % 1000;
   if (!ctx || M < 2 || N < 2 || K < 16 || (K % 16) || (M % 2) || (N % 2) || nbatch < 1 || iters < 1) {
     set_error("wv_dbg_gemm_bench: bad argument");
     return WV_E_BADARG;
@@ -158,6 +162,11 @@ int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t 
   g.sA = (int64_t)M * K; g.sB = (int64_t)N * K; g.sC = (int64_t)M * N;
   g.lda = a_kc ? K : M; g.ldb = b_kc ? K : N; g.ldc = N;
   g.M = M; g.N = N; g.kb = 0; g.ke = K; g.alpha = 1.0; g.beta = 0.0; g.nbatch = nbatch;
+  if (mode == 1) { g.tri = 1; g.klo_mode = 1; }
+  if (mode == 2) { g.tri = 1; g.beta = 1.0; g.alpha = -1e-3; }
+  if (mode == 3) { g.khi_mode = 2; }
+  if (mode == 4) { g.tri = 1; }
+  if (mode == 5) { g.beta = 1.0; g.alpha = -1e-3; }
   hipEvent_t a, b;
   WV_HIP_TRY(hipEventCreate(&a));
   WV_HIP_TRY(hipEventCreate(&b));
@@ -169,7 +178,11 @@ int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t 
   WV_HIP_TRY(hipGetLastError());
   float ms = 0;
   WV_HIP_TRY(hipEventElapsedTime(&ms, a, b));
-  if (tflops_out) *tflops_out = 2.0 * M * N * (double)K * nbatch * iters / (ms * 1e-3) / 1e12;
+  double fl = 2.0 * M * N * (double)K;
+  if (mode == 1) fl = (double)M * M * M / 3.0;
+  if (mode == 2 || mode == 4) fl = (double)M * M * K;
+  if (mode == 3) fl = (double)M * N * K;
+  if (tflops_out) *tflops_out = fl * nbatch * iters / (ms * 1e-3) / 1e12;
   if (ms_out) *ms_out = ms / iters;
   hipEventDestroy(a); hipEventDestroy(b); hipFree(dA); hipFree(dB); hipFree(dC);
   return WV_OK;
@@ -199,7 +212,9 @@ int32_t wv_dbg_stage(wv_problem* h, int32_t col, const double* theta, int32_t wh
   size_t bytes = sizeof(double) * mat;
   if (what == 0) src = p.Kbuf + (int64_t)g.slot0 * mat;
   if (what >= 1) {
-    trtri(p, st, g.slot0, 1);
+    // what == 1 exercises the production schedule (recursive factor + inverse) from a fresh Gram
+    launch_gram(p, st, g.slot0, 1, 0);
+    factor_inverse(p, st, g.slot0, 1);
     src = p.Mbuf + (int64_t)g.slot0 * mat;
   }
   if (what >= 2) {

@@ -6,7 +6,7 @@
 // per batch slot s (max_batch slots):
 //   Kbuf   [Npad][Npad]      K_y (lower) -> L (lower, in place) -> K_y^-1 (lower)
 //   Mbuf   [Npad][Npad]      M = L^-1 (lower; strictly upper part stays zero)
-//   Pbuf   [Npad][64]        TRTRI panel temporary
+//   Pbuf   [Npad/2+64][Npad/2+64] + [Npad][64]  L21 scratch of the recursive factorisation
 //   theta  [n_params]        constrained parameter table of the slot's fit
 //   r, z, alpha [Npad]       residual y - c, L^-1 r, K_y^-1 r
 // Npad = N rounded up to a multiple of 64; padded rows/cols of K_y are the identity so
@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -63,9 +64,10 @@ struct GemmArgs {
   int32_t lda, ldb, ldc;
   int32_t M, N;        // extent of C
   int32_t kb, ke;      // default contraction range
-  // kmode 0: [kb, ke).  1: [kb, min(ke, m0 + BM + koff))  (triangular A, TRTRI)
-  //       2: [max(kb, m0 + koff), ke)                    (LAUUM)
-  int32_t kmode, koff;
+  // triangular operands trim the contraction range per tile (m0 / n0 = tile origin in C):
+  //   klo_mode 1: kb = max(kb, m0 + koff)        2: kb = max(kb, n0 + koff)
+  //   khi_mode 1: ke = min(ke, m0 + BM + koff)   2: ke = min(ke, n0 + BN + koff)
+  int32_t klo_mode, khi_mode, koff;
   int32_t tri;         // 1: skip tiles whose first column (n0 + tri_off) > last row (m0 + BM - 1)
   int32_t tri_off;
   double alpha, beta;
@@ -134,6 +136,7 @@ struct Problem {
   int64_t workspace_bytes = 0;
   std::vector<Group> groups;
   StageTimer timer;
+  int64_t pbuf_elems() const { int64_t h = Npad / 2 + NB; return std::max<int64_t>(h * h, Npad * NB); }
   int nblk() const { return (int)(Npad / NB); }
   int ntiles() const { int t = (int)(Npad / GT); return t * (t + 1) / 2; }
 };
@@ -155,6 +158,7 @@ int trace_nwg(const Problem& p);
 void cholesky(Problem& p, hipStream_t st, int slot0, int nb);
 void trtri(Problem& p, hipStream_t st, int slot0, int nb);
 void lauum(Problem& p, hipStream_t st, int slot0, int nb);
+void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb);  // recursive potrf + trtri
 
 std::string build_devspec(const Spec& s, DevSpec& out);
 

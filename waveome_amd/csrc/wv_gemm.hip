@@ -105,8 +105,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   if (g.tri && n0 + g.tri_off > m0 + BM - 1) return;
 
   int kb = g.kb, ke = g.ke;
-  if (g.kmode == 1) ke = min(ke, m0 + BM + g.koff);
-  if (g.kmode == 2) kb = max(kb, m0 + g.koff);
+  if (g.klo_mode == 1) kb = max(kb, m0 + g.koff);
+  if (g.klo_mode == 2) kb = max(kb, n0 + g.koff);
+  if (g.khi_mode == 1) ke = min(ke, m0 + BM + g.koff);
+  if (g.khi_mode == 2) ke = min(ke, n0 + BN + g.koff);
 
   const double* __restrict__ A = g.A + (int64_t)b * g.sA;
   const double* __restrict__ B = g.B + (int64_t)b * g.sB;
@@ -131,6 +133,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
 
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb) / KC;
+  // Tiles whose contraction range starts at a tile-dependent offset (klo_mode) walk K downwards
+  // from the common end so that all tiles streaming the same panel touch the same rows at the same
+  // time (L2 reuse); the others already share their start.
+  const int kstep = g.klo_mode ? -KC : KC;
+  kb = g.klo_mode ? ke - KC : kb;
   if (nchunk > 0) {
     TA::gload(ra, A, g.lda, m0, g.M, kb, tid);
     TB::gload(rb, B, g.ldb, n0, g.N, kb, tid);
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunk) {
-      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * KC, tid);
-      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * KC, tid);
+      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, tid);
+      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, tid);
     }
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
