@@ -86,11 +86,20 @@ def inv_softplus(x):
 
 
 def sigmoid(u):
+    """d softplus / du, evaluated without cancellation for u << 0 (a variance driven to 1e-15 by
+    the Horseshoe prior sits at u ~ -34, where 0.5 (1 + tanh(u/2)) has ~5 % rounding error)."""
     u = np.asarray(u, dtype=np.float64)
-    return 0.5 * (1.0 + np.tanh(0.5 * u))
+    e = np.exp(-np.abs(u))
+    return np.where(u >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+
+
+U_FLOOR = -340.0  # positive parameters saturate at softplus(-340) ~ 2e-148 (never 0, and (x/s)^2 stays a
+                  # normal double, so the Horseshoe log-density stays finite); below the floor
+                  # d theta / du = 0.  The product mirrors this (wv_spec.cpp).
 
 
 def constrain_one(kind, u):
+    u = max(float(u), U_FLOOR) if kind != "identity" else u
     if kind == "softplus":
         return float(softplus(u))
     if kind == "softplus_shift":
@@ -112,7 +121,7 @@ def unconstrain_one(kind, x):
 
 def dconstrain_one(kind, u):
     if kind in ("softplus", "softplus_shift"):
-        return float(sigmoid(u))
+        return float(sigmoid(u)) if u >= U_FLOOR else 0.0
     return 1.0
 
 
@@ -341,10 +350,12 @@ def horseshoe_dlogpdf(x, scale):
     d1 = float(sigmoid(t)) / (1.0 - g)
     den = h + b * xx
     inner = g / xx - (1.0 - g) / den**2
-    dinner = -g / (xx * xx) + 2.0 * (1.0 - g) * (dh + b) / den**3
     l1p = math.log1p(inner)
-    d2 = dinner / ((1.0 + inner) * l1p)
-    return (d1 + d2) * dxx
+    # d2 * dxx with numerator and denominator multiplied by xx^2 (xx^2 underflows for x < 1e-77):
+    #   dinner / (1 + inner) = (-g + xx^2 c1) / (xx (xx + g - xx (1-g)/den^2)),  dxx / xx = 2 / x
+    c1 = 2.0 * (1.0 - g) * (dh + b) / den**3
+    d2dxx = (-g + xx * xx * c1) / ((xx + g - xx * (1.0 - g) / den**2) * l1p) * (2.0 / x)
+    return d1 * dxx + d2dxx
 
 
 def log_prior(spec, theta):

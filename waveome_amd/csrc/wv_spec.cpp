@@ -31,9 +31,20 @@ int n_factor_params(int type) {
   }
 }
 
-double softplus(double u) { return u > 0 ? u + std::log1p(std::exp(-u)) : std::log1p(std::exp(u)); }
+// positive parameters saturate at softplus(-340) ~ 2e-148: never exactly 0, where the Horseshoe
+// log-density is +inf (gpflow exposes the same idea as default_positive_minimum)
+constexpr double kUFloor = -340.0;  // theta >= ~2e-148 so (x/s)^2 stays a normal double
+double softplus(double u) {
+  if (u < kUFloor) u = kUFloor;
+  return u > 0 ? u + std::log1p(std::exp(-u)) : std::log1p(std::exp(u));
+}
 double inv_softplus(double x) { return x + std::log(-std::expm1(-x)); }
-double sigmoid(double u) { return 0.5 * (1.0 + std::tanh(0.5 * u)); }
+// d softplus/du without cancellation for u << 0 (pruned variances sit at u ~ -34)
+double sigmoid(double u) {
+  if (u < kUFloor) return 0.0;
+  const double e = std::exp(-std::fabs(u));
+  return u >= 0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+}
 
 // tfd.Horseshoe._log_prob restated (see oracle/gp_oracle.py: horseshoe_logpdf).
 double horseshoe_logpdf(double x, double scale, double* dlogp) {
@@ -54,8 +65,10 @@ double horseshoe_logpdf(double x, double scale, double* dlogp) {
     double dq = 20.0 / 47.0 * pw * std::pow(xx, pw - 1.0);
     double dh = -1.5 * std::sqrt(xx) / ((1.0 + x15) * (1.0 + x15)) + h_inf * dq / ((1.0 + q) * (1.0 + q));
     double d1 = sigmoid(t) / (1.0 - g);
-    double dinner = -g / (xx * xx) + 2.0 * (1.0 - g) * (dh + b) / (den * den * den);
-    *dlogp = (d1 + dinner / ((1.0 + inner) * l1p)) * dxx;
+    // d2 * dxx with numerator and denominator multiplied by xx^2 (xx^2 underflows for x < 1e-77)
+    double c1 = 2.0 * (1.0 - g) * (dh + b) / (den * den * den);
+    double d2dxx = (-g + xx * xx * c1) / ((xx + g - xx * (1.0 - g) / (den * den)) * l1p) * (2.0 / x);
+    *dlogp = d1 * dxx + d2dxx;
   }
   return -softplus(t) + std::log(l1p) + c;
 }
