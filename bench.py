@@ -93,21 +93,32 @@ def main():
 
     P = args.tasks * world
     dist = torch = None
+    dev = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dev = torch.device("cuda", local_rank)
+        backend = os.environ.get("WV_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a 1-GPU box
+        ndev = torch.cuda.device_count()
+        my_dev = local_rank % max(1, ndev)
+        if backend == "nccl":
+            torch.cuda.set_device(my_dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", my_dev))
+            dev = torch.device("cuda", my_dev)
+        else:
+            dist.init_process_group(backend)
         X_h, Y_h = make_inputs(P) if rank == 0 else (None, None)
-        Xt = parallel.broadcast_array(X_h, 0, dev)  # RCCL broadcast of the design matrix
+        Xt = parallel.broadcast_array(X_h, 0, dev)  # RCCL broadcast of the design matrix (N x D)
         Yt = parallel.broadcast_array(Y_h, 0, dev)  # and of the outputs (P x N)
-        torch.cuda.synchronize()
-        ctx = Context(local_rank)
+        ctx = Context(my_dev)
         spec = headline_spec()
-        prob = Problem(ctx, None, None, spec, max_batch=args.batch, x_device_ptr=Xt.data_ptr(),
-                       y_device_ptr=Yt.data_ptr(), shape=(N_HEAD, D_HEAD, P))
+        if dev is not None:
+            torch.cuda.synchronize()
+            prob = Problem(ctx, None, None, spec, max_batch=args.batch, x_device_ptr=Xt.data_ptr(),
+                           y_device_ptr=Yt.data_ptr(), shape=(N_HEAD, D_HEAD, P))
+        else:
+            X_h, Y_h = Xt.numpy(), Yt.numpy()
+            prob = Problem(ctx, X_h, Y_h.T, spec, max_batch=args.batch)
     else:
         X_h, Y_h = make_inputs(P)
         ctx = Context(0)
@@ -122,12 +133,13 @@ def main():
         ctx.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if dev is not None:
+                torch.cuda.synchronize()
 
     def step():
         res = prob.fit(my_cols, U0, opts)
         rec = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
-        return parallel.gather_records(rec, my_cols, P, device=(dev if world > 1 else None)), res
+        return parallel.gather_records(rec, my_cols, P, device=dev), res
 
     for _ in range(args.warmup):
         step()
@@ -140,7 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stages = prob.stage_times()

@@ -1,10 +1,10 @@
 import sys; sys.path.insert(0,'.')
 from waveome_amd.engine import Context
 c=Context(0)
-print("mode 0 full, 1 lauum-like (useful flops N^3/3), 2 syrk-like (M*M*K), 3 trimmed (M*N*K)")
+print("bn 128 = v1 (forced via WV_GEMM2_MIN=0 env not set here -> auto), bn 256 = v2; mode 0 full 1 lauum 2 syrk 3 trimmed")
 for (M,N,K,nb,akc,bkc,mode) in [(2048,2048,2048,32,0,0,0),(2048,2048,2048,32,0,0,1),(2048,2048,2048,128,0,0,1),
                                (1024,1024,1024,128,1,1,0),(1024,1024,1024,128,1,1,2),(1024,1024,1024,128,1,1,3),(1024,1024,1024,128,1,0,0),
-                               (512,512,512,128,1,1,0),(512,512,512,128,1,1,2),(256,256,256,128,1,1,0),(128,128,128,128,1,1,0),(64,64,64,128,1,1,0)]:
-    bn = 128 if N > 64 else 64
-    tf,ms=c.gemm_bench(M,N,K,bool(akc),bool(bkc),bn+1000*mode,nb,3)
-    print(f"M{M} N{N} K{K} nb{nb} akc{akc} bkc{bkc} mode{mode}: {tf:6.1f} TF/s  {ms*1e3:9.1f} us", flush=True)
+                               (512,512,512,128,1,1,0),(512,512,512,128,1,1,2),(256,256,256,128,1,1,0)]:
+    for bn in (128,):
+        tf,ms=c.gemm_bench(M,N,K,bool(akc),bool(bkc),bn+1000*mode,nb,3)
+        print(f"M{M} N{N} K{K} nb{nb} akc{akc} bkc{bkc} mode{mode} bn{bn}: {tf:6.1f} TF/s  {ms*1e3:9.1f} us", flush=True)

@@ -73,6 +73,7 @@ struct GemmArgs {
   double alpha, beta;
   int32_t nbatch;
   int32_t tiles_m, tiles_n;
+  int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
 };
 
 enum Stage {

@@ -26,6 +26,7 @@
 // bank-conflict free with ds_read_b64:
 //   K-contiguous operand  [rows][16+2]   (row stride 18 doubles: 18*r mod 32 distinct, even)
 //   K-strided   operand   [16][rows+16]  (row stride = 16 mod 32 doubles)
+#include <algorithm>
 #include <cstdlib>
 
 #include "wv_device.hpp"
@@ -85,11 +86,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
   constexpr int NJ = BN / 32;  // B fragments per wave
-  __shared__ __attribute__((aligned(16))) double sA[2][TA::SIZE];
-  __shared__ __attribute__((aligned(16))) double sB[2][TB::SIZE];
+  // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
+  // image of half the C tile in the epilogue
+  constexpr int LDC = BN + 2;
+  constexpr int SMEM = 2 * (TA::SIZE + TB::SIZE) > 64 * LDC ? 2 * (TA::SIZE + TB::SIZE) : 64 * LDC;
+  __shared__ __attribute__((aligned(16))) double smem[SMEM];
+  double(*sA)[TA::SIZE] = reinterpret_cast<double(*)[TA::SIZE]>(smem);
+  double(*sB)[TB::SIZE] = reinterpret_cast<double(*)[TB::SIZE]>(smem + 2 * TA::SIZE);
 
-  // ---- block -> (batch, tile) with same-matrix tiles kept on one XCD (L2 reuse of panels) ----
-  const int tiles = g.tiles_m * g.tiles_n;
+  // ---- block -> (batch, tile) with same-matrix tiles kept on one XCD (L2 reuse of panels).
+  // g.tiles_live counts only the tiles that do work (lower tiles when g.tri): no workgroup is
+  // launched just to exit - an empty workgroup still holds one of the CU's two slots for ~2 us. ----
+  const int tiles = g.tiles_live;
   int b, tile;
   if (g.nbatch >= 8) {
     int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -100,9 +108,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
     b = blockIdx.x / tiles;
     tile = blockIdx.x % tiles;
   }
-  const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+  // longest contraction first: ranges trimmed from above (khi_mode) grow with the tile index
+  if (g.khi_mode && !g.tri) tile = tiles - 1 - tile;
+  int tm, tn;
+  if (g.tri) {
+    tm = 0;
+    for (;;) {
+      const int cnt = min(g.tiles_n, max(0, (tm * BM + BM - 1 - g.tri_off) / BN + 1));
+      if (tile < cnt) break;
+      tile -= cnt;
+      ++tm;
+    }
+    tn = tile;
+  } else {
+    tm = tile / g.tiles_n;
+    tn = tile % g.tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
-  if (g.tri && n0 + g.tri_off > m0 + BM - 1) return;
 
   int kb = g.kb, ke = g.ke;
   if (g.klo_mode == 1) kb = max(kb, m0 + g.koff);
@@ -131,6 +153,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
+  // Per-wave contraction range at 64-row / (BN/2)-column granularity: a wave whose 64 x BN/2
+  // sub-tile needs fewer chunks (triangular operand) or none (above the diagonal of a lower-only
+  // product) skips the MFMAs - it still loads and synchronises - and its SIMD time goes to the
+  // co-resident workgroup.
+  int wkb = kb, wke = ke;
+  {
+    const int wr = m0 + wm * 64, wc = n0 + wn * (BN / 2);
+    if (g.klo_mode == 1) wkb = max(wkb, wr + g.koff);
+    if (g.klo_mode == 2) wkb = max(wkb, wc + g.koff);
+    if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
+    if (g.khi_mode == 2) wke = min(wke, wc + BN / 2 + g.koff);
+    if (g.tri && wc + g.tri_off > wr + 63) wke = wkb;  // nothing to do
+  }
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb) / KC;
   // Tiles whose contraction range starts at a tile-dependent offset (klo_mode) walk K downwards
@@ -153,6 +188,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
     }
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
+    const int kc0 = kb + c * kstep;  // first k of this chunk
+    if (kc0 >= wkb && kc0 < wke)
 #pragma unroll OCC == 1 ? 4 : 1
     for (int s = 0; s < KC / 4; ++s) {
       double af[4];
@@ -178,32 +215,77 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
 
   // ---- epilogue: C = beta*C + alpha*acc.  D lane 16 i' + 4 blk + j of accumulator (i, j, r)
   // is row 16 i + 4 blk + i', column 16 j + 4((blk + r) & 3) + j of the wave tile. ----
+  // ---- epilogue: C = beta*C + alpha*acc, staged through LDS so that C is read and written as
+  // full rows (64 lanes x 16 B = 1 KB per wave instruction) instead of 32-byte fragments.
+  // D lane 16 i' + 4 blk + jj of accumulator (i, j, r) is row 16 i + 4 blk + i', column
+  // 16 j + 4((blk + r) & 3) + jj of the wave tile. ----
   const double alpha = g.alpha, beta = g.beta;
+  constexpr int PAIRS = BN / 2;             // double2 per row
+  constexpr int NROWIT = 64 * PAIRS / 256;  // row-pieces per thread per half
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + 4 * fblk + fk;
+  for (int h = 0; h < 2; ++h) {
+    // issue this half's C reads first: their latency hides behind the LDS staging and the barrier
+    d2 cv[NROWIT];
+    if (beta != 0.0) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + brot[r];
-        if (m < g.M && n < g.N) {
-          double* cp = C + (int64_t)m * g.ldc + n;
-          double v = alpha * acc[i][j][r];
-          if (beta != 0.0) v += beta * (*cp);
-          *cp = v;
-        }
+      for (int it = 0; it < NROWIT; ++it) {
+        const int q = tid + 256 * it, row = q / PAIRS, cp = q % PAIRS;
+        const int m = m0 + 64 * h + row, n = n0 + 2 * cp;
+        cv[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const d2*>(C + (int64_t)m * g.ldc + n) : d2{0.0, 0.0};
       }
     }
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            smem[(i * 16 + 4 * fblk + fk) * LDC + wn * (BN / 2) + j * 16 + brot[r]] = alpha * acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NROWIT; ++it) {
+      const int q = tid + 256 * it, row = q / PAIRS, cp = q % PAIRS;
+      const int m = m0 + 64 * h + row, n = n0 + 2 * cp;
+      if (m < g.M && n < g.N) {
+        d2 v = *reinterpret_cast<const d2*>(smem + row * LDC + 2 * cp);
+        if (beta != 0.0) {
+          v.x += beta * cv[it].x;
+          v.y += beta * cv[it].y;
+        }
+        *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
+void launch_gemm2(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc);
+
 void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int bn) {
+  // large outputs go to the 256 x 128 LDS-DMA kernel (wv_gemm2.hip); bn == 256 forces it
+  static int v2_min = -1;
+  if (v2_min < 0) {
+    const char* e = getenv("WV_GEMM2_MIN");
+    v2_min = e ? atoi(e) : 0;  // off by default: no faster on the triangular forms
+  }
+  if (bn == 256 || (bn == 128 && v2_min > 0 && a_in.M >= v2_min && a_in.N >= 128)) {
+    launch_gemm2(st, a_in, a_kc, b_kc);
+    return;
+  }
   GemmArgs a = a_in;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + bn - 1) / bn;
   if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
   int tiles = a.tiles_m * a.tiles_n;
+  if (a.tri) {
+    tiles = 0;
+    for (int tm = 0; tm < a.tiles_m; ++tm)
+      tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / bn + 1));
+  }
+  a.tiles_live = tiles;
+  if (tiles <= 0) return;
   int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
   dim3 g(grid), blk(256);
   static int occ = -1;
