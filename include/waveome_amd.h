@@ -205,11 +205,30 @@ int32_t wv_fit(wv_problem* prob, const int32_t* col_idx, int32_t n_tasks,
                const wv_lbfgs_opts* opts, double* theta_u_inout, double* loss_out, double* lml_out,
                int32_t* n_iter_out, int32_t* n_eval_out, int32_t* status_out);
 
-/* Posterior prediction at the optimum for ONE task: mean and variance of f (and
- * of y = f + noise when include_noise != 0) at Xnew (M x D).  Replaces
- * predict_f / predict_y (waveome/model_classes.py:526-544) for the exact GP. */
+/* wv_fit with a per-task Horseshoe scale (= 1 / penalization_factor of that output) overriding the
+ * spec's prior scales; prior_scale = NULL is wv_fit.  Used by the iterated analytic penalisation
+ * factor, which differs per output (waveome/model_search.py:273-299, 332-375). */
+int32_t wv_fit_penalized(wv_problem* prob, const int32_t* col_idx, int32_t n_tasks,
+                         const wv_lbfgs_opts* opts, const double* prior_scale, double* theta_u_inout,
+                         double* loss_out, double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out,
+                         int32_t* status_out);
+
+/* Posterior prediction for ONE task at constrained table theta: mean and variance of f (and of
+ * y = f + noise when include_noise != 0).  Replaces predict_f / predict_y
+ * (waveome/model_classes.py:526-544).  ABI v1 implements Xnew = NULL: prediction at the N
+ * training inputs (the only use on this path: model_search.py:340 and utilities.py:629);
+ * other Xnew returns WV_E_UNSUPPORTED. mean_out / var_out hold N doubles (either may be NULL). */
 int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out);
+
+/* Means the reference's whitened SVGP (inducing points = X, q_mu at its optimum) predicts at the
+ * training inputs when the kernel is replaced by the sub-sum of additive terms in term_masks[m]
+ * (bit t = term t of the spec) while q_mu is kept:  mean_m = chol(K_m + jitter I) q_mu + c,
+ * q_mu = chol(K_all + jitter I)' alpha.  This is what `model_copy.kernel.kernels.pop(k)` followed by
+ * `predict_y` computes in calc_feature_importance_components (waveome/utilities.py:614-707);
+ * jitter = gpflow's default 1e-6.  means_out is n_masks x N. */
+int32_t wv_whitened_means(wv_problem* prob, int32_t col, const double* theta, const uint64_t* term_masks,
+                          int32_t n_masks, double jitter, double* means_out);
 
 /* Timing of the device stages of the most recent wv_value_grad / wv_fit on this
  * problem, measured with HIP events on the stream the kernels ran on.

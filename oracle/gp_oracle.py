@@ -426,6 +426,46 @@ def fit(spec, X, y, maxiter=50000, maxfun=None, ftol=2.220446049250313e-09, gtol
 
 
 # --------------------------------------------------------------------------
+# post-fit quantities on the path: predict_y at the training inputs (model_search.py:340) and the
+# leave-one-component-out means of calc_feature_importance_components (utilities.py:614-707)
+# --------------------------------------------------------------------------
+def predict_train(spec, theta, X, y, include_noise=True):
+    """Exact-GP posterior mean / variance of f (or y) at the training inputs."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    K = gram(spec, theta, X)
+    s2 = theta[spec["noise"]]
+    Ky = K + s2 * np.eye(N)
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    sol = np.linalg.solve(Ky, np.column_stack([_resid(spec, theta, y), K]))
+    mean = c + K @ sol[:, 0]
+    var = np.diag(K) - np.einsum("ij,ji->i", K, sol[:, 1:]) + (s2 if include_noise else 0.0)
+    return mean, var
+
+
+def sub_spec(spec, term_ids):
+    out = dict(spec)
+    out["terms"] = [spec["terms"][t] for t in term_ids]
+    return out
+
+
+def whitened_means(spec, theta, X, y, term_sets, jitter=1e-6):
+    """mean_m = chol(K_m + jitter I) q_mu + c with q_mu = chol(K + jitter I)' alpha: gpflow's whitened
+    SVGP conditional with Z = X when the kernel is swapped for a sub-sum and q_mu is kept."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    K = gram(spec, theta, X)
+    alpha = np.linalg.solve(K + theta[spec["noise"]] * np.eye(N), _resid(spec, theta, y))
+    q_mu = np.linalg.cholesky(K + jitter * np.eye(N)).T @ alpha
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    out = []
+    for ts in term_sets:
+        Km = gram(sub_spec(spec, ts), theta, X) if len(ts) else np.zeros((N, N))
+        out.append(np.linalg.cholesky(Km + jitter * np.eye(N)) @ q_mu + c)
+    return np.array(out)
+
+
+# --------------------------------------------------------------------------
 # small spec builders used by tests / bench (GPflow defaults: all ones, c = 0)
 # --------------------------------------------------------------------------
 def make_spec(D, terms, mean=True, noise_init=1.0, prior_scale=None):

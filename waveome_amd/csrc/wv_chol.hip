@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const double* __restrict__ 
   if (wave == 0) aall[(int64_t)b * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// generic lower-triangular products on any N x N buffer: out = T in (trans = false) or T' in
+void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* in, double* out, int slot0,
+                 int nb, bool trans) {
+  if (!trans)
+    hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
+  else
+    hipLaunchKernelGGL(trmv_t_kernel, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
+}
+
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha) {
   p.timer.begin(st, ST_SOLVE);
   hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,

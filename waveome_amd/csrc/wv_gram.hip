@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevSpec* __restrict__ s
                                                    const double* __restrict__ X,
                                                    const double* __restrict__ theta_all,
                                                    double* __restrict__ Kall, int64_t N,
-                                                   int64_t Npad, int D, int slot0, int write_upper) {
+                                                   int64_t Npad, int D, int slot0, int write_upper,
+                                                   uint64_t term_mask, double diag_override) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const int16_t* slots = sp->fslots;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevSpec* __restrict__ s
 #pragma unroll
     for (int c = 0; c < 4; ++c) sum[a][c] = 0.0;
   for (int term = 0; term < sp->n_terms; ++term) {
+    if (!((term_mask >> term) & 1ull)) continue;  // leave-component-out Gram matrices
     const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
     for (int f = f0; f < f1; ++f) {
       eval_factor<false>(sp->factors[f], slots, th, t, k, dummy_w, dummy_s);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevSpec* __restrict__ s
 #pragma unroll
       for (int c = 0; c < 4; ++c) sum[a][c] += prod[a][c];
   }
-  const double noise = th[sp->noise_param];
+  const double noise = diag_override >= 0.0 ? diag_override : th[sp->noise_param];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
@@ -421,12 +423,19 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
   for (int p = tid; p < np; p += 256) out[p] = acc[p] + acc[np + p] + acc[2 * np + p] + acc[3 * np + p];
 }
 
+void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
+  dim3 grid(p.ntiles(), nb), blk(256);
+  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
+  hipLaunchKernelGGL(gram_kernel, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D, slot0,
+                     0, term_mask, diag);
+}
+
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper) {
   dim3 grid(p.ntiles(), nb), blk(256);
   size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
   p.timer.begin(st, ST_GRAM);
   hipLaunchKernelGGL(gram_kernel, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
-                     p.D, slot0, write_upper);
+                     p.D, slot0, write_upper, ~0ull, -1.0);
   p.timer.end(st);
   p.timer.work(ST_GRAM, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }

@@ -154,14 +154,14 @@ double Spec::dconstrain(int k, double u) const {
   return (t == WV_T_IDENTITY) ? 1.0 : sigmoid(u);
 }
 
-double Spec::log_prior(const double* theta, double* grad) const {
+double Spec::log_prior(const double* theta, double* grad, double scale_override) const {
   double tot = 0;
   if (grad) std::memset(grad, 0, sizeof(double) * n_params());
   for (int i = 0; i < n_params(); ++i) {
     const auto& p = params[i];
     if (p.trainable && p.prior_scale > 0) {
       double d = 0;
-      tot += horseshoe_logpdf(theta[i], p.prior_scale, grad ? &d : nullptr);
+      tot += horseshoe_logpdf(theta[i], scale_override > 0 ? scale_override : p.prior_scale, grad ? &d : nullptr);
       if (grad) grad[i] = d;
     }
   }

@@ -31,7 +31,8 @@ struct Spec {
   void unconstrain(const double* theta, double* u) const;
   // d theta_p / d u for trainable k at unconstrained value u_k
   double dconstrain(int k, double u) const;
-  double log_prior(const double* theta, double* grad /*n_params or null*/) const;
+  // scale_override > 0 replaces every prior's scale (per-task penalisation factors)
+  double log_prior(const double* theta, double* grad /*n_params or null*/, double scale_override = -1.0) const;
 };
 
 int n_factor_params(int type);

@@ -150,8 +150,9 @@ class Problem:
                                           _lib.as_dp(grad), _lib.as_ip(st)), "wv_value_grad")
         return loss, grad, st
 
-    def fit(self, cols, U0, opts=None):
-        """Fit len(cols) tasks; returns dict of arrays (u, loss, lml, nit, nfev, status)."""
+    def fit(self, cols, U0, opts=None, prior_scale=None):
+        """Fit len(cols) tasks; returns dict of arrays (u, loss, lml, nit, nfev, status).
+        prior_scale: optional per-task Horseshoe scale (1 / penalization_factor of that output)."""
         cols = np.ascontiguousarray(cols, dtype=np.int32)
         U = np.array(np.atleast_2d(U0), dtype=np.float64, order="C", copy=True)
         T = len(cols)
@@ -160,10 +161,33 @@ class Problem:
         opts = opts or lbfgs_opts()
         loss, lml = np.empty(T), np.empty(T)
         nit, nfev, st = (np.empty(T, dtype=np.int32) for _ in range(3))
-        _lib.check(self.lib.wv_fit(self.handle, _lib.as_ip(cols), T, C.byref(opts), _lib.as_dp(U),
-                                   _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit), _lib.as_ip(nfev),
-                                   _lib.as_ip(st)), "wv_fit")
+        ps = None
+        if prior_scale is not None:
+            ps = np.ascontiguousarray(np.broadcast_to(prior_scale, (T,)), dtype=np.float64)
+        _lib.check(self.lib.wv_fit_penalized(self.handle, _lib.as_ip(cols), T, C.byref(opts),
+                                             _lib.as_dp(ps) if ps is not None else None, _lib.as_dp(U),
+                                             _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit),
+                                             _lib.as_ip(nfev), _lib.as_ip(st)), "wv_fit_penalized")
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
+
+    def predict(self, col, theta, include_noise=True):
+        """Posterior mean / variance at the training inputs (predict_y when include_noise)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        mean, var = np.empty(self.N), np.empty(self.N)
+        _lib.check(self.lib.wv_predict(self.handle, int(col), _lib.as_dp(theta), None, 0, int(bool(include_noise)),
+                                       _lib.as_dp(mean), _lib.as_dp(var)), "wv_predict")
+        return mean, var
+
+    def whitened_means(self, col, theta, term_masks, jitter=1e-6):
+        """Training-input means of the whitened SVGP with the kernel restricted to the additive terms in
+        each mask while q_mu is kept (what utilities.py:614-707 computes by popping a kernel)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        masks = np.ascontiguousarray(term_masks, dtype=np.uint64)
+        out = np.empty((len(masks), self.N))
+        _lib.check(self.lib.wv_whitened_means(self.handle, int(col), _lib.as_dp(theta),
+                                              masks.ctypes.data_as(C.POINTER(C.c_uint64)), len(masks),
+                                              float(jitter), _lib.as_dp(out)), "wv_whitened_means")
+        return out
 
     # ---- timing ----
     STAGES = ("gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",

@@ -18,8 +18,9 @@ import numpy as np
 from . import kernels as K
 from .engine import Context, Problem, lbfgs_opts
 from .spec import ModelSpec
-from .utilities import (calc_bic, find_variance_components, print_kernel_names,
-                        search_through_kernel_list_)
+from .spec import _expand
+from .utilities import (calc_bic, calc_feature_importance_components, find_variance_components,
+                        print_kernel_names, search_through_kernel_list_)
 
 _default_ctx: Optional[Context] = None
 
@@ -119,6 +120,53 @@ class PSVGP:
 
     def training_loss(self, data=None):
         return -self.log_posterior_density(data)
+
+    # ---- prediction at the training inputs (the only Xnew this path uses) ----------------
+    def _check_xnew(self, Xnew):
+        if Xnew is not None:
+            Xnew = np.asarray(Xnew, dtype=np.float64)
+            if Xnew.shape != self.data[0].shape or not np.array_equal(Xnew, self.data[0]):
+                raise NotImplementedError("prediction is implemented at the training inputs only")
+
+    def predict_f(self, Xnew=None, full_cov=False, full_output_cov=False):
+        self._check_xnew(Xnew)
+        spec, prob = self._problem()
+        mean, var = prob.predict(0, spec.theta(), include_noise=False)
+        prob.close()
+        return mean[:, None], var[:, None]
+
+    def predict_y(self, Xnew=None, full_cov=False, full_output_cov=False):
+        self._check_xnew(Xnew)
+        spec, prob = self._problem()
+        mean, var = prob.predict(0, spec.theta(), include_noise=True)
+        prob.close()
+        return mean[:, None], var[:, None]
+
+    def component_means(self, data=None):
+        """[full model, without additive component 0, 1, ...] training means of the whitened SVGP the
+        reference evaluates in calc_feature_importance_components (utilities.py:614-707)."""
+        spec, prob = self._problem()
+        comps = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
+        # additive component k owns a contiguous run of flattened terms (products of sums expand)
+        counts = [len(_expand(k)) for k in comps]
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        n_terms = int(starts[-1])
+        full = (1 << n_terms) - 1
+        masks = [full]
+        if self.kernel.name == "sum":
+            for k in range(len(comps)):
+                own = ((1 << counts[k]) - 1) << int(starts[k])
+                masks.append(full & ~own)
+        out = prob.whitened_means(0, spec.theta(), masks)
+        prob.close()
+        return out
+
+    def get_feature_importances(self, data=None, return_value="log_bf"):
+        """model_classes.py:546-573."""
+        data = self.data if data is None else data
+        self.feature_importances = list(calc_feature_importance_components(model=self, data=data,
+                                                                           return_value=return_value))
+        return None
 
     def calc_metric(self, data=None, metric="BIC"):
         assert metric == "BIC", "Only BIC currently allowed."

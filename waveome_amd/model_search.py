@@ -105,8 +105,6 @@ class GPSearch:
             raise NotImplementedError("only outcome_likelihood='gaussian' is implemented on the GPU path")
         if optimization_options.get("optimizer", "scipy") != "scipy":
             raise NotImplementedError("only optimization_options={'optimizer': 'scipy'} is implemented")
-        if penalization_factor is None:
-            raise NotImplementedError("penalization_factor=None (iterated analytic factor) is not implemented yet")
         if sparse_options:
             warnings.warn("sparse_options are ignored: the GPU path is the exact GP (all N points)")
         if random_seed is not None:
@@ -127,9 +125,28 @@ class GPSearch:
         Xn = self.X.to_numpy(dtype=np.float64)
         Yn = self.Y.to_numpy(dtype=np.float64)
         P = Yn.shape[1]
+        # penalization_factor=None: analytic factor 2 * 1.1 * sigma_hat * sqrt(N) * Phi^-1(1 - 0.1 / (2 p)) per
+        # output, then up to num_factor_iter re-fits with sigma_hat = sqrt(mean predict_y variance)
+        # (model_search.py:273-299, 332-375)
+        iterating = penalization_factor is None
+        if iterating:
+            import scipy.stats
+
+            from .utilities import find_variance_components
+
+            if num_restart > 0:
+                raise NotImplementedError("penalization_factor=None with num_restart > 0")
+            num_params = len(np.asarray(find_variance_components(full_kernel, sum_reduce=False)).reshape(-1))
+            zq = scipy.stats.norm().ppf(1 - (0.1 / (2 * num_params)))
+            sigma_hat = np.ones(P) if num_factor_iter == 0 else np.std(Yn, axis=0)  # np.std(Series): ddof = 0
+            pf = 2 * 1.1 * sigma_hat * np.sqrt(Xn.shape[0]) * zq
+            if verbose:
+                print("Setting penalization factor to", f" {pf}")
+        else:
+            pf = np.full(P, float(penalization_factor))
         # template model: structure, defaults and priors shared by every output
         template = PSVGP(Xn, Yn[:, :1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
-                         penalized_options={"penalization_factor": penalization_factor},
+                         penalized_options={"penalization_factor": float(pf[0])},
                          variational_options=variational_options, context=context)
         spec = template._spec()
         u0 = spec.unconstrain()
@@ -147,12 +164,42 @@ class GPSearch:
         nt = spec.n_trainable
         opts = lbfgs_opts(maxiter=optimization_options.get("num_opt_iter", 50000))
 
+        has_prior = bool(np.all(pf > 0))
+        if not has_prior and np.any(pf > 0):
+            raise ValueError("penalization factors must be all positive or all zero")
+
         def fit_shard(ids):
             mb = max_batch or min(len(ids), _default_batch(len(Xn)))
             prob = Problem(ctx, Xn, Yn, spec, max_batch=max(1, mb))
-            res = prob.fit(cols[ids], starts[ids], opts)
+            scale = (1.0 / pf[cols[ids]]) if has_prior else None
+            res = prob.fit(cols[ids], starts[ids], opts, prior_scale=scale)
+            u, pf_used = res["u"], pf[cols[ids]].copy()
+            extra = np.zeros((len(ids), 2))  # total iterations / evaluations over the factor re-fits
+            if iterating:
+                live = np.arange(len(ids))
+                for _ in range(int(num_factor_iter)):
+                    keep = []
+                    for k in live:
+                        _, var = prob.predict(int(cols[ids][k]), spec.constrain(u[k]), include_noise=True)
+                        new_pf = 2 * 1.1 * np.sqrt(np.mean(var)) * np.sqrt(Xn.shape[0]) * zq
+                        if verbose:
+                            print("New penalization factor:" f" {new_pf}")
+                        if abs(new_pf - pf_used[k]) <= 1e-3 or new_pf > pf_used[k]:
+                            continue  # converged, or a larger factor: keep the current fit (:354-364)
+                        pf_used[k] = new_pf
+                        keep.append(k)
+                    live = np.array(keep, dtype=np.int64)
+                    if len(live) == 0:
+                        break
+                    r2 = prob.fit(cols[ids][live], u[live], opts, prior_scale=1.0 / pf_used[live])
+                    u[live] = r2["u"]
+                    for key in ("loss", "lml", "status"):
+                        res[key][live] = r2[key]
+                    extra[live, 0] += r2["nit"]
+                    extra[live, 1] += r2["nfev"]
             prob.close()
-            return np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"], res["u"]])
+            return np.column_stack([res["loss"], res["lml"], res["nit"] + extra[:, 0], res["nfev"] + extra[:, 1],
+                                    res["status"], pf_used, u])
 
         rec = parallel.sharded_map(len(cols), fit_shard) if world > 1 else fit_shard(np.arange(len(cols)))
         self.fit_records = rec
@@ -161,15 +208,16 @@ class GPSearch:
             block = rec[p * n_starts:(p + 1) * n_starts]
             best = block[np.argmin(block[:, 0])]  # lowest training loss over restarts
             mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
-                        penalized_options={"penalization_factor": penalization_factor},
+                        penalized_options={"penalization_factor": float(best[5])},
                         variational_options=variational_options, context=context)
             mspec = mod._spec()
-            mspec.assign_theta(mspec.constrain(best[5:5 + nt]))
+            mspec.assign_theta(mspec.constrain(best[6:6 + nt]))
             mod.fit_result = {"loss": best[0], "lml": best[1], "nit": int(best[2]), "nfev": int(best[3]),
                               "status": int(best[4])}
             mod.optimizer = "scipy"
             mod.cut_kernel_components(data=(Xn, Yn[:, p:p + 1]))
             mod.update_kernel_name()
+            mod.get_feature_importances(data=(Xn, Yn[:, p:p + 1]))  # model_search.py:383-387
             self.models[feat] = mod
         c = len(self.out_names)
         elapsed_time = np.round((time.time() - start_time) / 60, 1)

@@ -78,3 +78,77 @@ def search_through_kernel_list_(kernel_list, list_type="sum", X=None):
     if len(out_list) == 1:
         return out_list[0]
     return K.Empty()
+
+
+def _gaussian_logdensity(x, mu, var):
+    """gpflow.logdensities.gaussian."""
+    return -0.5 * (np.log(2 * np.pi) + np.log(var) + np.square(mu - x) / var)
+
+
+def calc_deviance_explained(model, data=None, model_mu=None, model_var=None, base_mu=None, base_var=None,
+                            aggregate=True, return_deviance_explained=True, return_loglik=False):
+    """Gaussian branch of waveome/utilities.py:517-611 (the likelihood on this path)."""
+    y = np.asarray(data[1], dtype=np.float64)
+    y_var = np.var(y)
+    sat_ll = _gaussian_logdensity(y, y, y_var)
+    base_ll = _gaussian_logdensity(y, np.mean(y) if base_mu is None else base_mu, y_var)
+    mod_ll = _gaussian_logdensity(y, model_mu, y_var)
+    if return_loglik:
+        return base_ll, mod_ll, sat_ll
+    if aggregate:
+        null_deviance = max(0, 2 * np.sum(sat_ll - base_ll))
+        model_deviance = max(0, 2 * np.sum(sat_ll - mod_ll))
+        deviance_explained = 1 - (model_deviance / null_deviance) if null_deviance > 0 else 0
+    else:
+        null_deviance = np.clip(2 * (sat_ll - base_ll), a_min=0, a_max=np.inf)
+        model_deviance = np.clip(2 * (sat_ll - mod_ll), a_min=0, a_max=np.inf)
+        deviance_explained = 1 - np.divide(model_deviance, null_deviance,
+                                           out=np.ones_like(model_deviance, dtype="float"),
+                                           where=(null_deviance != 0))
+    if return_deviance_explained:
+        return deviance_explained
+    return null_deviance, model_deviance
+
+
+def calc_feature_importance_components(model, data=None, return_value="log_bf"):
+    """waveome/utilities.py:614-707: per additive component, the fit lost when the component is removed
+    from the kernel while the (whitened) variational mean is kept; last entry = 1 - deviance explained.
+    `model.component_means(data)` supplies [full, without component 0, 1, ...] training means (GPU)."""
+    de_list = []
+    k = model.kernel
+    means = model.component_means(data)
+    y = np.asarray(data[1], dtype=np.float64).reshape(-1, 1)
+    full_mu_hat = means[0].reshape(-1, 1)
+    null_lls, mod_lls, sat_lls = calc_deviance_explained(model=model, data=(data[0], y), model_mu=full_mu_hat,
+                                                         return_deviance_explained=False, aggregate=False,
+                                                         return_loglik=True)
+    if np.sum(sat_lls) >= np.sum(mod_lls) and np.sum(mod_lls) >= np.sum(null_lls):
+        full_de = 1 - (-2 * np.sum(mod_lls - sat_lls) / (-2 * np.sum(null_lls - sat_lls)))
+        full_de = max(min(1, full_de), 0)
+    else:
+        full_de = 0
+    if k.name == "sum":
+        for k_idx in range(len(k.kernels)):
+            mod_mu_hat = means[1 + k_idx].reshape(-1, 1)
+            null_lls, sub_mod_lls, sat_lls = calc_deviance_explained(
+                model=model, data=(data[0], y), model_mu=mod_mu_hat, return_deviance_explained=False,
+                aggregate=False, return_loglik=True)
+            if return_value == "statistic":
+                scaled_de = max(np.round(-2 * (np.sum(sub_mod_lls) - np.sum(mod_lls)), 1), 0)
+            elif return_value == "log_bf":
+                scaled_de = np.round(np.sum(mod_lls) - np.sum(sub_mod_lls), 1)
+            else:
+                scaled_de = 1 - (-2 * np.sum(sub_mod_lls - mod_lls) / (-2 * np.sum(null_lls - mod_lls)))
+                scaled_de = np.round(max(min(1, scaled_de), 0), 3)
+            de_list += [scaled_de]
+    else:
+        if k.name == "constant":
+            de_list += [0.0]
+        elif return_value == "statistic":
+            de_list += [np.round(-2 * (np.sum(null_lls) - np.sum(mod_lls)), 1)]
+        elif return_value == "log_bf":
+            de_list += [np.round((np.sum(mod_lls) - np.sum(null_lls)), 1)]
+        else:
+            de_list += [np.round(full_de, 3)]
+    de_list += [np.round(1 - full_de, 3)]
+    return de_list
