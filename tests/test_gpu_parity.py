@@ -401,3 +401,108 @@ def test_iterated_penalization_factor(ctx):
         implied = 2 * 1.1 * np.sqrt(np.mean(var)) * np.sqrt(N) * zq
         assert mod.fit_result["status"] in (0, 2, 3)
         assert np.isfinite(implied) and implied > 0
+
+
+# ---------------------------------------------------------------- edge cases and the other BASELINE configs
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129, 200])
+def test_ragged_and_tiny_sizes(ctx, N):
+    """Empty-ish and ragged inputs: N below / at / just above the 64-row block, odd N."""
+    from waveome_amd.engine import Problem
+
+    X, Y = _data(30 + N, max(N, 4))
+    X, Y = X[:N], Y[:N]
+    ms = _with_priors(ModelSpec(K.SquaredExponential(active_dims=[0]) + K.Categorical(active_dims=[3]), 4,
+                                mean_function=K.ConstantMean()))
+    prob = Problem(ctx, X, Y, ms, max_batch=3)
+    u = ms.unconstrain()
+    loss, grad, st = prob.value_grad([0, 2], np.stack([u, u + 0.2]))
+    d = ms.to_dict()
+    for b, (c, uu) in enumerate([(0, u), (2, u + 0.2)]):
+        fo, go = o.objective(d, uu, X, Y[:, c])
+        assert st[b] == 0 and loss[b] == pytest.approx(fo, rel=1e-11, abs=1e-10)
+        np.testing.assert_allclose(grad[b], go, rtol=1e-8, atol=1e-9)
+    prob.close()
+
+
+def test_bad_arguments_are_rejected(ctx):
+    from waveome_amd._lib import WaveomeAmdError
+    from waveome_amd.engine import Problem
+
+    X, Y = _data(1, 50)
+    ms = ModelSpec(K.SquaredExponential(active_dims=[0]), 4)
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    with pytest.raises(WaveomeAmdError, match="column index"):
+        prob.lml([7], ms.theta()[None, :])
+    with pytest.raises(ValueError):
+        prob.fit([0, 1], ms.unconstrain()[None, :])  # U0 shape mismatch
+    with pytest.raises(WaveomeAmdError):
+        Problem(ctx, X, Y, ModelSpec(K.SquaredExponential(active_dims=[0]), 3), max_batch=2)  # D mismatch
+    many = K.Sum([K.Periodic(K.SquaredExponential(active_dims=[d % 4])) for d in range(40)])
+    with pytest.raises(WaveomeAmdError, match="staged features"):
+        Problem(ctx, X, Y, ModelSpec(many, 4), max_batch=2)  # 40 periods x (sin, cos) > 64 LDS feature slots
+    prob.close()
+
+
+def test_config_c4_ihmp_shape_six_structures(ctx):
+    """configs[3] shape: N = 1500, D = 8 (unit + 2 categorical + 5 numeric), one structure per base kernel
+    {SE, M12, M32, M52, Periodic, Lin} per numeric column + unit categorical; LML parity at N not a multiple
+    of 64 with a 100-level unit column."""
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(9102 + 4)
+    N, D = 1500, 8
+    X = np.empty((N, D))
+    X[:, 0] = rng.integers(0, 100, N)
+    X[:, 1] = rng.integers(0, 5, N)
+    X[:, 2] = rng.integers(0, 3, N)
+    Xn = rng.uniform(-3, 3, size=(N, 5))
+    X[:, 3:] = (Xn - Xn.mean(0)) / Xn.std(0, ddof=1)
+    Y = np.stack([np.sin(X[:, 3] * (1 + p)) + 0.3 * (X[:, 1] == p) + 0.05 * X[:, 0] / 100 + 0.1 * rng.normal(size=N)
+                  for p in range(3)], axis=1)
+    bases = {"se": K.SquaredExponential, "m12": K.Matern12, "m32": K.Matern32, "m52": K.Matern52,
+             "per": lambda active_dims: K.Periodic(K.SquaredExponential(active_dims=active_dims)), "lin": K.Lin}
+    for name, mk in bases.items():
+        kern = K.Sum([K.Categorical(active_dims=[0])] + [mk(active_dims=[c]) for c in range(3, 8)])
+        ms = _with_priors(ModelSpec(kern, D, mean_function=K.ConstantMean()))
+        prob = Problem(ctx, X, Y, ms, max_batch=3)
+        th = ms.theta()
+        th[ms.noise] = 0.2
+        lml, st = prob.lml([0, 1, 2], np.tile(th, (3, 1)))
+        d = ms.to_dict()
+        for p in range(3):
+            ref = o.lml(d, th, X, Y[:, p])
+            assert st[p] == 0 and abs(lml[p] - ref) <= 1e-10 * abs(ref), (name, p, lml[p], ref)
+        prob.close()
+
+
+def test_config_c3_composite_n4096(ctx):
+    """configs[2]: N = 4096, D = 5 (4 numeric + 1 categorical), full_kernel_build(kerns=[SE, Periodic(SE)])
+    = 17 terms / 41 kernel parameters; LML and gradient (directional finite difference) at bench size."""
+    from waveome_amd.engine import Problem
+    from waveome_amd.regularization import full_kernel_build
+
+    rng = np.random.default_rng(9102 + 3)
+    N = 4096
+    Xn = rng.uniform(-3, 3, size=(N, 4))
+    X = np.column_stack([(Xn - Xn.mean(0)) / Xn.std(0, ddof=1), rng.integers(0, 5, N).astype(float)])
+    y = np.sin(2 * X[:, 0]) + 0.5 * np.sin(1.3 * X[:, 1]) + 0.4 * (X[:, 4] == 2) + 0.1 * rng.normal(size=N)
+    kern = full_kernel_build(cat_vars=[4], num_vars=[0, 1, 2, 3], return_sum=True,
+                             kerns=[K.SquaredExponential(), K.Periodic()])
+    ms = _with_priors(ModelSpec(kern, 5, mean_function=K.ConstantMean()))
+    assert len(ms.terms) == 17
+    prob = Problem(ctx, X, y[:, None], ms, max_batch=2)
+    th = ms.theta()
+    lml, st = prob.lml([0], th[None, :])
+    ref = o.lml(ms.to_dict(), th, X, y)
+    assert st[0] == 0 and abs(lml[0] - ref) <= 1e-10 * abs(ref)
+    # gradient: directional central difference of the GPU objective itself (the dense oracle gradient at
+    # N = 4096 with 43 parameters needs ~6 GB of dK matrices)
+    u = ms.unconstrain()
+    dvec = rng.normal(size=len(u))
+    dvec /= np.linalg.norm(dvec)
+    h = 1e-5
+    l0, g0, _ = prob.value_grad([0], u[None, :])
+    lp, _, _ = prob.value_grad([0], (u + h * dvec)[None, :])
+    lm, _, _ = prob.value_grad([0], (u - h * dvec)[None, :])
+    assert float(g0[0] @ dvec) == pytest.approx((lp[0] - lm[0]) / (2 * h), rel=2e-6, abs=1e-6)
+    prob.close()
