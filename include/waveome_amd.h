@@ -215,9 +215,11 @@ int32_t wv_fit_penalized(wv_problem* prob, const int32_t* col_idx, int32_t n_tas
 
 /* Posterior prediction for ONE task at constrained table theta: mean and variance of f (and of
  * y = f + noise when include_noise != 0).  Replaces predict_f / predict_y
- * (waveome/model_classes.py:526-544).  ABI v1 implements Xnew = NULL: prediction at the N
- * training inputs (the only use on this path: model_search.py:340 and utilities.py:629);
- * other Xnew returns WV_E_UNSUPPORTED. mean_out / var_out hold N doubles (either may be NULL). */
+ * (waveome/model_classes.py:526-544) for the exact GP.  Xnew = NULL: the N training inputs
+ * (model_search.py:340, utilities.py:629) via mean_f = y - sigma^2 alpha, var_f = sigma^2 -
+ * sigma^4 diag(K_y^-1); otherwise Xnew is a host M x D matrix and mean_out / var_out hold M doubles
+ * (var_f = k(x*,x*) - |L^-1 k(X, x*)|^2, full_cov = False).  Either output may be NULL.  This call
+ * allocates temporary device memory (it is not on the optimisation loop). */
 int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out);
 

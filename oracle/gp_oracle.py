@@ -443,6 +443,21 @@ def predict_train(spec, theta, X, y, include_noise=True):
     return mean, var
 
 
+def predict(spec, theta, X, y, Xnew, include_noise=True):
+    """Exact-GP posterior mean / variance at new inputs (gpflow GPR.predict_f / predict_y, full_cov=False)."""
+    X = np.asarray(X, dtype=np.float64)
+    Xnew = np.asarray(Xnew, dtype=np.float64)
+    N = X.shape[0]
+    s2 = theta[spec["noise"]]
+    L = np.linalg.cholesky(gram(spec, theta, X) + s2 * np.eye(N))
+    Ks = gram(spec, theta, Xnew, X)
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    z = scipy.linalg.solve_triangular(L, _resid(spec, theta, y), lower=True)
+    V = scipy.linalg.solve_triangular(L, Ks.T, lower=True)
+    kss = np.array([gram(spec, theta, Xnew[i:i + 1])[0, 0] for i in range(len(Xnew))])
+    return c + V.T @ z, kss - np.sum(V * V, axis=0) + (s2 if include_noise else 0.0)
+
+
 def sub_spec(spec, term_ids):
     out = dict(spec)
     out["terms"] = [spec["terms"][t] for t in term_ids]

@@ -351,6 +351,19 @@ def test_predict_and_component_means_match_oracle(ctx):
         mo, vo = o.predict_train(d, th, X, Y[:, 1], include_noise=noise)
         np.testing.assert_allclose(mean, mo, rtol=0, atol=1e-9)
         np.testing.assert_allclose(var, vo, rtol=0, atol=1e-9)
+    # new inputs: 150 points (ragged against the 64-row tiles), covering seen and unseen categories
+    rngn = np.random.default_rng(8)
+    Xnew = rngn.normal(size=(150, 4))
+    Xnew[:, 3] = rngn.integers(0, 5, 150)
+    for noise in (True, False):
+        mean, var = prob.predict(1, th, include_noise=noise, Xnew=Xnew)
+        mo, vo = o.predict(d, th, X, Y[:, 1], Xnew, include_noise=noise)
+        np.testing.assert_allclose(mean, mo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(var, vo, rtol=0, atol=1e-9)
+    mean_tr, var_tr = prob.predict(1, th, include_noise=True, Xnew=X)  # general path at the training inputs
+    mo, vo = o.predict_train(d, th, X, Y[:, 1])
+    np.testing.assert_allclose(mean_tr, mo, atol=1e-9)
+    np.testing.assert_allclose(var_tr, vo, atol=1e-9)
     nt = len(d["terms"])
     sets = [list(range(nt))] + [[t for t in range(nt) if t != k] for k in range(nt)]
     masks = [sum(1 << t for t in s) for s in sets]

@@ -660,17 +660,68 @@ __global__ void kinv_diag_kernel(const double* __restrict__ Kinv, double* __rest
   if (i < N) out[i] = Kinv[i * Npad + i];
 }
 
+// mean[m] = sum_j Ks[m][j] alpha[j]   (one wave per row of the cross-Gram)
+__global__ __launch_bounds__(256) void cross_mean_kernel(const double* __restrict__ Ks,
+                                                         const double* __restrict__ alpha,
+                                                         double* __restrict__ mean, int64_t Mrow, int64_t Npad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  if (m >= Mrow) return;
+  double s = 0.0;
+  for (int64_t j = 2 * lane; j < Npad; j += 128) {
+    double2 k = *reinterpret_cast<const double2*>(Ks + m * Npad + j);
+    double2 a = *reinterpret_cast<const double2*>(alpha + j);
+    s += k.x * a.x + k.y * a.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) mean[m] = s;
+}
+
+// q[m] = sum_i V[i][m]^2   (V = M Ks', N x Mpad): threads along m, rows split over blockIdx.y
+__global__ __launch_bounds__(256) void colsumsq_kernel(const double* __restrict__ V, double* __restrict__ part,
+                                                       int64_t Npad, int64_t Mpad, int rows_per_block) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mpad) return;
+  const int64_t i0 = (int64_t)blockIdx.y * rows_per_block, i1 = min(Npad, i0 + rows_per_block);
+  double s = 0.0;
+  for (int64_t i = i0; i < i1; ++i) {
+    double v = V[i * Mpad + m];
+    s += v * v;
+  }
+  part[(int64_t)blockIdx.y * Mpad + m] = s;
+}
+
+// k(x, x) of the flattened Sum-of-Products at one point (host; used for predictive variances)
+static double kernel_diag_at(const Spec& s, const double* theta, const double* x) {
+  double tot = 0.0;
+  for (int t = 0; t < s.n_terms(); ++t) {
+    double prod = 1.0;
+    for (int f = s.term_start[t]; f < s.term_start[t + 1]; ++f) {
+      const wv_factor& fa = s.factors[f];
+      double xx = 0.0;
+      for (int d = 0; d < s.n_dims; ++d)
+        if (fa.dim_mask & (1u << d)) xx += x[d] * x[d];
+      double v;
+      switch (fa.type) {
+        case WV_K_LIN: v = theta[fa.param[0]] * xx; break;
+        case WV_K_POLY: v = std::pow(theta[fa.param[0]] * xx + theta[fa.param[1]], fa.degree); break;
+        case WV_K_EMPTY: v = 0.0; break;
+        default: v = theta[fa.param[0]];  // stationary, periodic, constant, categorical: the variance
+      }
+      prod *= v;
+    }
+    tot += prod;
+  }
+  return tot;
+}
+
 int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out) {
-  if (!h || !theta || col < 0 || col >= h->p.P) {
+  if (!h || !theta || col < 0 || col >= h->p.P || (Xnew && M < 1)) {
     set_error("wv_predict: bad argument");
     return WV_E_BADARG;
   }
-  if (Xnew != nullptr) {
-    set_error("wv_predict: only Xnew = NULL (prediction at the training inputs) is implemented");
-    return WV_E_UNSUPPORTED;
-  }
-  (void)M;
   Problem& p = h->p;
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = eval_one(p, col, theta);
@@ -680,21 +731,84 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     set_error("wv_predict: Gram matrix not positive definite at theta");
     return WV_E_BADARG;
   }
-  // K alpha = r - sigma^2 alpha  =>  mean_f = y - sigma^2 alpha;
-  // K - K K_y^-1 K = sigma^2 I - sigma^4 K_y^-1  =>  var_f = sigma^2 - sigma^4 diag(K_y^-1)
   const double s2 = theta[p.spec.noise_param];
-  std::vector<double> alpha(p.N), kd(p.N), y(p.N);
+  const double c = p.spec.mean_param >= 0 ? theta[p.spec.mean_param] : 0.0;
   hipStream_t st = g.stream;
-  hipLaunchKernelGGL(kinv_diag_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, st,
-                     p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad, p.dz + (int64_t)g.slot0 * p.Npad, p.Npad, p.N);
-  WV_HIP_TRY(hipMemcpyAsync(kd.data(), p.dz + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
-  WV_HIP_TRY(hipMemcpyAsync(alpha.data(), p.dalpha + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
-  WV_HIP_TRY(hipMemcpyAsync(y.data(), p.dY + (int64_t)col * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
-  WV_HIP_TRY(hipStreamSynchronize(st));
-  for (int64_t i = 0; i < p.N; ++i) {
-    if (mean_out) mean_out[i] = y[i] - s2 * alpha[i];
-    if (var_out) var_out[i] = s2 - s2 * s2 * kd[i] + (include_noise ? s2 : 0.0);
+  const int64_t mat = p.Npad * p.Npad;
+  if (Xnew == nullptr) {
+    // training inputs: K alpha = r - sigma^2 alpha  =>  mean_f = y - sigma^2 alpha;
+    // K - K K_y^-1 K = sigma^2 I - sigma^4 K_y^-1  =>  var_f = sigma^2 - sigma^4 diag(K_y^-1)
+    std::vector<double> alpha(p.N), kd(p.N), y(p.N);
+    hipLaunchKernelGGL(kinv_diag_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, st,
+                       p.Kbuf + (int64_t)g.slot0 * mat, p.dz + (int64_t)g.slot0 * p.Npad, p.Npad, p.N);
+    WV_HIP_TRY(hipMemcpyAsync(kd.data(), p.dz + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipMemcpyAsync(alpha.data(), p.dalpha + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipMemcpyAsync(y.data(), p.dY + (int64_t)col * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < p.N; ++i) {
+      if (mean_out) mean_out[i] = y[i] - s2 * alpha[i];
+      if (var_out) var_out[i] = s2 - s2 * s2 * kd[i] + (include_noise ? s2 : 0.0);
+    }
+    return WV_OK;
   }
+  // new inputs, in chunks of <= 4096 rows: Ks = K(Xnew, X); mean = Ks alpha + c;
+  // V = M Ks' (M = L^-1 from the factorisation); var_f = k(x*, x*) - colsum(V .* V)
+  const int64_t CH = 4096;
+  const int64_t chunk_pad = (std::min(M, CH) + GT - 1) / GT * GT;
+  const int nsplit = 16, rows_per = (int)((p.Npad + nsplit - 1) / nsplit);
+  double *dXn = nullptr, *dKs = nullptr, *dV = nullptr, *dmean = nullptr, *dpart = nullptr;
+  auto cleanup = [&]() {
+    for (double* q : {dXn, dKs, dV, dmean, dpart})
+      if (q) hipFree(q);
+  };
+  if (hipMalloc(&dXn, sizeof(double) * chunk_pad * p.D) != hipSuccess ||
+      hipMalloc(&dKs, sizeof(double) * chunk_pad * p.Npad) != hipSuccess ||
+      hipMalloc(&dV, sizeof(double) * p.Npad * chunk_pad) != hipSuccess ||
+      hipMalloc(&dmean, sizeof(double) * chunk_pad) != hipSuccess ||
+      hipMalloc(&dpart, sizeof(double) * nsplit * chunk_pad) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    set_error("wv_predict: device allocation failed");
+    return WV_E_OOM;
+  }
+  std::vector<double> hm(chunk_pad), hp((size_t)nsplit * chunk_pad);
+  const double* dth = p.dtheta + (int64_t)g.slot0 * p.spec.n_params();
+  for (int64_t m0 = 0; m0 < M; m0 += CH) {
+    const int64_t mc = std::min(CH, M - m0), mpad = (mc + GT - 1) / GT * GT;
+    hipMemsetAsync(dXn, 0, sizeof(double) * mpad * p.D, st);
+    hipMemcpyAsync(dXn, Xnew + m0 * p.D, sizeof(double) * mc * p.D, hipMemcpyHostToDevice, st);
+    launch_gram_rect(p, st, dXn, mc, mpad, dth, dKs);
+    hipLaunchKernelGGL(cross_mean_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, st, dKs,
+                       p.dalpha + (int64_t)g.slot0 * p.Npad, dmean, mc, p.Npad);
+    if (var_out) {
+      GemmArgs a{};
+      a.A = p.Mbuf + (int64_t)g.slot0 * mat;  // A(i, k) = M[i][k], lower triangular
+      a.B = dKs;                              // B(m, k) = Ks[m][k]
+      a.C = dV;
+      a.lda = (int)p.Npad; a.ldb = (int)p.Npad; a.ldc = (int)mpad;
+      a.M = (int)p.Npad; a.N = (int)mpad; a.kb = 0; a.ke = (int)p.Npad; a.khi_mode = 1;
+      a.alpha = 1.0; a.beta = 0.0; a.nbatch = 1;
+      launch_gemm(st, a, true, true, mpad > 64 ? 128 : 64);
+      hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((mpad + 255) / 256), nsplit), dim3(256), 0, st, dV, dpart,
+                         p.Npad, mpad, rows_per);
+      hipMemcpyAsync(hp.data(), dpart, sizeof(double) * nsplit * mpad, hipMemcpyDeviceToHost, st);
+    }
+    hipMemcpyAsync(hm.data(), dmean, sizeof(double) * mc, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+      cleanup();
+      set_error("wv_predict: HIP error in the prediction kernels");
+      return WV_E_HIP;
+    }
+    for (int64_t i = 0; i < mc; ++i) {
+      if (mean_out) mean_out[m0 + i] = hm[i] + c;
+      if (var_out) {
+        double q = 0.0;
+        for (int sblk = 0; sblk < nsplit; ++sblk) q += hp[(size_t)sblk * mpad + i];
+        var_out[m0 + i] = kernel_diag_at(p.spec, theta, Xnew + (m0 + i) * p.D) - q + (include_noise ? s2 : 0.0);
+      }
+    }
+  }
+  cleanup();
   return WV_OK;
 }
 

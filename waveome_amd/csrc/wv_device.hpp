@@ -148,6 +148,8 @@ inline int out_stride_for(int n_params) { return 3 + n_params; }
 // ---- kernel launchers (each enqueues on `st`, no host sync) ---------------------------
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper);
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag);
+void launch_gram_rect(Problem& p, hipStream_t st, const double* dXnew, int64_t Mrow, int64_t Mpad,
+                      const double* dtheta_row, double* out);
 void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* in, double* out, int slot0,
                  int nb, bool trans);
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0);

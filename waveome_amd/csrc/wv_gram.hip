@@ -320,6 +320,67 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevSpec* __restrict__ s
   }
 }
 
+// Rectangular cross-Gram K(Xrow, Xcol) for prediction at new inputs: rows = Mrow new points,
+// columns = the N training points, no noise, padded entries zero.  One 64 x 64 tile per workgroup.
+__global__ __launch_bounds__(256) void gram_rect_kernel(const DevSpec* __restrict__ sp,
+                                                        const double* __restrict__ Xrow,
+                                                        const double* __restrict__ Xcol,
+                                                        const double* __restrict__ th,
+                                                        double* __restrict__ out, int64_t Mrow,
+                                                        int64_t N, int64_t ldo, int D, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int16_t* slots = sp->fslots;
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
+  const int tid = threadIdx.x;
+  double* fi = smem;
+  double* fj = smem + sp->n_feat * GT;
+  stage_features(fi, sp, Xrow, th, ti * GT, Mrow, D, tid);
+  stage_features(fj, sp, Xcol, th, tj * GT, N, D, tid);
+  __syncthreads();
+  TileCtx t{fi, fj, tid >> 4, tid & 15};
+  double sum[4][4], k[4][4], prod[4][4], dummy_w[4][4], dummy_s[3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sum[a][c] = 0.0;
+  for (int term = 0; term < sp->n_terms; ++term) {
+    const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
+    for (int f = f0; f < f1; ++f) {
+      eval_factor<false>(sp->factors[f], slots, th, t, k, dummy_w, dummy_s);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) prod[a][c] = (f == f0) ? k[a][c] : prod[a][c] * k[a][c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum[a][c] += prod[a][c];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
+      v[c] = (i < Mrow && j < N) ? sum[a][c] : 0.0;
+    }
+    double* dst = out + i * ldo + (int64_t)tj * GT + 4 * t.tx;
+    *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+  }
+}
+
+void launch_gram_rect(Problem& p, hipStream_t st, const double* dXnew, int64_t Mrow, int64_t Mpad,
+                      const double* dtheta_row, double* out) {
+  const int tiles_n = (int)(p.Npad / GT);
+  dim3 grid((unsigned)((Mpad / GT) * tiles_n)), blk(256);
+  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
+  hipLaunchKernelGGL(gram_rect_kernel, grid, blk, sh, st, p.dspec, dXnew, p.dX, dtheta_row, out, Mrow, p.N,
+                     p.Npad, p.D, tiles_n);
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -170,12 +170,20 @@ class Problem:
                                              _lib.as_ip(nfev), _lib.as_ip(st)), "wv_fit_penalized")
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
 
-    def predict(self, col, theta, include_noise=True):
-        """Posterior mean / variance at the training inputs (predict_y when include_noise)."""
+    def predict(self, col, theta, include_noise=True, Xnew=None):
+        """Posterior mean / variance (predict_y when include_noise, else predict_f) at the training inputs
+        (Xnew=None) or at an (M, D) array of new inputs."""
         theta = np.ascontiguousarray(theta, dtype=np.float64)
-        mean, var = np.empty(self.N), np.empty(self.N)
-        _lib.check(self.lib.wv_predict(self.handle, int(col), _lib.as_dp(theta), None, 0, int(bool(include_noise)),
-                                       _lib.as_dp(mean), _lib.as_dp(var)), "wv_predict")
+        if Xnew is None:
+            M, xp = self.N, None
+        else:
+            Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+            if Xnew.ndim != 2 or Xnew.shape[1] != self.D:
+                raise ValueError(f"Xnew must be (M, {self.D})")
+            M, xp = Xnew.shape[0], _lib.as_dp(Xnew)
+        mean, var = np.empty(M), np.empty(M)
+        _lib.check(self.lib.wv_predict(self.handle, int(col), _lib.as_dp(theta), xp, M if Xnew is not None else 0,
+                                       int(bool(include_noise)), _lib.as_dp(mean), _lib.as_dp(var)), "wv_predict")
         return mean, var
 
     def whitened_means(self, col, theta, term_masks, jitter=1e-6):

@@ -122,23 +122,30 @@ class PSVGP:
         return -self.log_posterior_density(data)
 
     # ---- prediction at the training inputs (the only Xnew this path uses) ----------------
-    def _check_xnew(self, Xnew):
-        if Xnew is not None:
-            Xnew = np.asarray(Xnew, dtype=np.float64)
-            if Xnew.shape != self.data[0].shape or not np.array_equal(Xnew, self.data[0]):
-                raise NotImplementedError("prediction is implemented at the training inputs only")
+    def _xnew(self, Xnew):
+        """None / the training matrix itself -> the cheap training-input path; anything else is passed on."""
+        if Xnew is None:
+            return None
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        if Xnew.shape == self.data[0].shape and np.array_equal(Xnew, self.data[0]):
+            return None
+        return Xnew
 
     def predict_f(self, Xnew=None, full_cov=False, full_output_cov=False):
-        self._check_xnew(Xnew)
+        """Posterior mean / variance of f (model_classes.py:526-534); full_cov is not supported."""
+        if full_cov or full_output_cov:
+            raise NotImplementedError("full_cov=True is not implemented")
         spec, prob = self._problem()
-        mean, var = prob.predict(0, spec.theta(), include_noise=False)
+        mean, var = prob.predict(0, spec.theta(), include_noise=False, Xnew=self._xnew(Xnew))
         prob.close()
         return mean[:, None], var[:, None]
 
     def predict_y(self, Xnew=None, full_cov=False, full_output_cov=False):
-        self._check_xnew(Xnew)
+        """Posterior mean / variance of y (model_classes.py:536-544)."""
+        if full_cov or full_output_cov:
+            raise NotImplementedError("full_cov=True is not implemented")
         spec, prob = self._problem()
-        mean, var = prob.predict(0, spec.theta(), include_noise=True)
+        mean, var = prob.predict(0, spec.theta(), include_noise=True, Xnew=self._xnew(Xnew))
         prob.close()
         return mean[:, None], var[:, None]
 
