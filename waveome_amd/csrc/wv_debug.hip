@@ -166,6 +166,7 @@ int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t 
   if (mode == 2) { g.tri = 1; g.beta = 1.0; g.alpha = -1e-3; }
   if (mode == 3) { g.khi_mode = 2; }
   if (mode == 4) { g.tri = 1; }
+  if (mode == 6) { g.khi_mode = 1; }
   if (mode == 5) { g.beta = 1.0; g.alpha = -1e-3; }
   hipEvent_t a, b;
   WV_HIP_TRY(hipEventCreate(&a));
@@ -181,7 +182,7 @@ int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t 
   double fl = 2.0 * M * N * (double)K;
   if (mode == 1) fl = (double)M * M * M / 3.0;
   if (mode == 2 || mode == 4) fl = (double)M * M * K;
-  if (mode == 3) fl = (double)M * N * K;
+  if (mode == 3 || mode == 6) fl = (double)M * N * K;
   if (tflops_out) *tflops_out = fl * nbatch * iters / (ms * 1e-3) / 1e12;
   if (ms_out) *ms_out = ms / iters;
   hipEventDestroy(a); hipEventDestroy(b); hipFree(dA); hipFree(dB); hipFree(dC);

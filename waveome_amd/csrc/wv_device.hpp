@@ -74,6 +74,7 @@ struct GemmArgs {
   int32_t nbatch;
   int32_t tiles_m, tiles_n;
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
+  int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
 };
 
 enum Stage {

@@ -110,8 +110,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   }
   // longest contraction first: ranges trimmed from above (khi_mode) grow with the tile index
   if (g.khi_mode && !g.tri) tile = tiles - 1 - tile;
+  // When the contraction length depends on the tile COLUMN it repeats with period tiles_n in launch
+  // order; workgroups appear to be dealt to shader engines round-robin, so a power-of-two period
+  // leaves some engines with only short tiles (PMC: 1.3 instead of 2 resident waves per SIMD).
+  // Rotating the order by a different amount for every matrix spreads all lengths over all engines.
+  if ((g.khi_mode == 2 || g.klo_mode == 2) && !g.tri) tile = (tile + 3 * (b >> 3) + (b & 7)) % tiles;
   int tm, tn;
   if (g.tri) {
+    // (rotating lower-only products or row-dependent lengths the same way measured no gain)
+    if (g.rot_tri > 0) tile = (tile + ((5 * (b >> 3) + (b & 7)) & 31)) % tiles;
     tm = 0;
     for (;;) {
       const int cnt = min(g.tiles_n, max(0, (tm * BM + BM - 1 - g.tri_off) / BN + 1));
@@ -285,6 +292,11 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
       tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / bn + 1));
   }
   a.tiles_live = tiles;
+  {
+    static int rt = -1;
+    if (rt < 0) { const char* e = getenv("WV_ROT_TRI"); rt = e ? atoi(e) : 0; }
+    a.rot_tri = rt;
+  }
   if (tiles <= 0) return;
   int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
   dim3 g(grid), blk(256);
