@@ -256,7 +256,7 @@ __device__ inline void tri_decode(int t, int& ti, int& tj) {
   tj = t - i * (i + 1) / 2;
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(const DevSpec* __restrict__ sp,
+__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ sp,
                                                    const double* __restrict__ X,
                                                    const double* __restrict__ theta_all,
                                                    double* __restrict__ Kall, int64_t N,
