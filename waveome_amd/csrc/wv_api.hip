@@ -274,7 +274,7 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_out) hipHostFree(g.h_out);
     if (g.h_status) hipHostFree(g.h_status);
   }
-  void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
+  void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
                   p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus};
   for (void* q : ptrs)
     if (q) hipFree(q);
@@ -333,6 +333,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
             alloc((void**)&p.dspec, sizeof(DevSpec)) &&
             alloc((void**)&p.Kbuf, sizeof(double) * mat * max_batch) &&
             alloc((void**)&p.Mbuf, sizeof(double) * mat * max_batch) &&
+            alloc((void**)&p.MTbuf, sizeof(double) * mat * max_batch) &&
             alloc((void**)&p.Pbuf, sizeof(double) * p.pbuf_elems() * max_batch) &&
             alloc((void**)&p.dtheta, sizeof(double) * np * max_batch) &&
             alloc((void**)&p.dr, sizeof(double) * Np * max_batch) &&
@@ -353,6 +354,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   WV_HIP_TRY(hipMemset(p.dY, 0, sizeof(double) * Np * P));
   WV_HIP_TRY(hipMemset(p.Kbuf, 0, sizeof(double) * mat * max_batch));
   WV_HIP_TRY(hipMemset(p.Mbuf, 0, sizeof(double) * mat * max_batch));
+  WV_HIP_TRY(hipMemset(p.MTbuf, 0, sizeof(double) * mat * max_batch));
   WV_HIP_TRY(hipMemset(p.dalpha, 0, sizeof(double) * Np * max_batch));
   WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * np * max_batch));
   WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));

@@ -51,6 +51,7 @@ __device__ inline void inv_level(const double* __restrict__ L, double* __restric
 // ONE barrier (the column buffer is double-buffered).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Kall,
                                                          double* __restrict__ Mall,
+                                                         double* __restrict__ MTall,
                                                          double* __restrict__ logdet,
                                                          int32_t* __restrict__ status,
                                                          int64_t Npad, int nblk, int slot0, int j0) {
@@ -159,11 +160,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
     *reinterpret_cast<double2*>(dst) = make_double2(X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1]);
     *reinterpret_cast<double2*>(dst + 2) = make_double2(X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]);
   }
+  if (MTall) {  // transposed image of the inverse block
+    double* MT = MTall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * ty + r;
+      double* dst = MT + (int64_t)i * Npad + 4 * tx;
+      *reinterpret_cast<double2*>(dst) = make_double2(X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i]);
+      *reinterpret_cast<double2*>(dst + 2) = make_double2(X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]);
+    }
+  }
 }
 
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
   p.timer.begin(st, ST_POTRF_DIAG);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.dlogdet,
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
                      p.dstatus, p.Npad, p.nblk(), slot0, j0);
   p.timer.end(st);
 }
@@ -429,51 +440,54 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
   double* K0 = p.Kbuf + (int64_t)slot0 * mat;
   double* M0 = p.Mbuf + (int64_t)slot0 * mat;
-  double* S0 = p.Pbuf + (int64_t)slot0 * p.pbuf_elems();
+  double* MT0 = p.MTbuf + (int64_t)slot0 * mat;
+  double* S0 = p.Pbuf + (int64_t)slot0 * p.pbuf_elems();  // holds S' (h1 x h2): K-strided image of S
   const int64_t sS = p.pbuf_elems();
   fi_node(p, st, slot0, nb, o, h1);
-  {  // S = A21 * M11'
+  {  // S = A21 * M11'   written transposed;  B(n, k) = M11[n][k] = MT[k][n]  (K-strided)
     GemmArgs a = base_args(p, slot0, nb);
     a.A = K0 + (o + h1) * Np + o;
-    a.B = M0 + o * Np + o;  // B(n, k) = M11[n][k]
-    a.C = S0; a.sC = sS; a.ldc = (int)h1;
+    a.B = MT0 + o * Np + o;
+    a.C = nullptr;
+    a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
     p.timer.begin(st, ST_CHOL_TRSM);
-    launch_gemm(st, a, true, true, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
-  {  // A22 -= S S'
+  {  // A22 -= S S'   with A(m, k) = S'[k][m], B(n, k) = S'[k][n]
     GemmArgs a = base_args(p, slot0, nb);
-    a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h1;
+    a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h2;
     a.C = K0 + (o + h1) * Np + (o + h1);
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
     a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
     p.timer.begin(st, ST_CHOL_TRAIL);
-    launch_gemm(st, a, true, true, h2 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, h2 > 64 ? 128 : 64);
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
-  {  // T = S * M11 over the dead A21 block
+  {  // T = S * M11 over the dead A21 block;  A(m, k) = S'[k][m],  B(n, k) = M11[k][n]
     GemmArgs a = base_args(p, slot0, nb);
-    a.A = S0; a.sA = sS; a.lda = (int)h1;
-    a.B = M0 + o * Np + o;  // B(n, k) = M11[k][n]
+    a.A = S0; a.sA = sS; a.lda = (int)h2;
+    a.B = M0 + o * Np + o;
     a.C = K0 + (o + h1) * Np + o;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.klo_mode = 2;
     p.timer.begin(st, ST_TRTRI_A);
-    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, h1 > 64 ? 128 : 64);
     p.timer.end(st);
     p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
   fi_node(p, st, slot0, nb, o + h1, h2);
-  {  // M21 = -M22 * T
+  {  // M21 = -M22 * T  (also written transposed into MT);  A(m, k) = M22[m][k] = MT[k][m]
     GemmArgs a = base_args(p, slot0, nb);
-    a.A = M0 + (o + h1) * Np + (o + h1);
+    a.A = MT0 + (o + h1) * Np + (o + h1);
     a.B = K0 + (o + h1) * Np + o;  // B(n, k) = T[k][n]
     a.C = M0 + (o + h1) * Np + o;
+    a.CT = MT0 + o * Np + (o + h1); a.sCT = mat; a.ldct = (int)Np; a.tout = 2;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h2; a.khi_mode = 1; a.alpha = -1.0;
     p.timer.begin(st, ST_TRTRI_B);
-    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, h1 > 64 ? 128 : 64);
     p.timer.end(st);
     p.timer.work(ST_TRTRI_B, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }

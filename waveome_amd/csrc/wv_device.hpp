@@ -6,6 +6,7 @@
 // per batch slot s (max_batch slots):
 //   Kbuf   [Npad][Npad]      K_y (lower) -> L (lower, in place) -> K_y^-1 (lower)
 //   Mbuf   [Npad][Npad]      M = L^-1 (lower; strictly upper part stays zero)
+//   MTbuf  [Npad][Npad]      M' (upper): K-strided image of M for the products that read M by rows
 //   Pbuf   [Npad/2+64][Npad/2+64] + [Npad][64]  L21 scratch of the recursive factorisation
 //   theta  [n_params]        constrained parameter table of the slot's fit
 //   r, z, alpha [Npad]       residual y - c, L^-1 r, K_y^-1 r
@@ -73,6 +74,9 @@ struct GemmArgs {
   double alpha, beta;
   int32_t nbatch;
   int32_t tiles_m, tiles_n;
+  double* CT;          // transposed output (tout != 0): CT[n][m], batch stride sCT, leading dimension ldct
+  int64_t sCT;
+  int32_t ldct, tout;
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
 };
@@ -129,7 +133,7 @@ struct Problem {
   // device memory
   double *dX = nullptr, *dY = nullptr;
   DevSpec* dspec = nullptr;
-  double *Kbuf = nullptr, *Mbuf = nullptr, *Pbuf = nullptr;
+  double *Kbuf = nullptr, *Mbuf = nullptr, *MTbuf = nullptr, *Pbuf = nullptr;
   double *dtheta = nullptr, *dr = nullptr, *dz = nullptr, *dalpha = nullptr;
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
   double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials

@@ -27,6 +27,7 @@
 //   K-contiguous operand  [rows][16+2]   (row stride 18 doubles: 18*r mod 32 distinct, even)
 //   K-strided   operand   [16][rows+16]  (row stride = 16 mod 32 doubles)
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "wv_device.hpp"
@@ -81,7 +82,9 @@ struct Tile {
 
 // OCC = waves per SIMD the register allocator may assume (2: <= 256 VGPRs, two workgroups per CU;
 // 1: up to 512 VGPRs, one workgroup per CU, k-steps fully unrolled and software-pipelined).
-template <bool A_KC, bool B_KC, int BN, int OCC>
+// TOUT: 0 = write C; 1 = write only C' (to g.CT, leading dimension g.ldct); 2 = write both.
+// The transposed copy keeps later products on the K-strided (fastest) load path.
+template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT>
 __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
@@ -261,7 +264,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
           v.x += beta * cv[it].x;
           v.y += beta * cv[it].y;
         }
-        *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
+        if (TOUT != 1) *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
+      }
+    }
+    if (TOUT != 0) {
+      // transposed copy: thread -> (column n, row pair), 32 lanes x 16 B = 512 B of one row of C'
+      double* __restrict__ CT = g.CT + (int64_t)b * g.sCT;
+#pragma unroll
+      for (int it = 0; it < NROWIT; ++it) {
+        const int q = tid + 256 * it, n = q >> 5, mp = q & 31;
+        const int m = m0 + 64 * h + 2 * mp, nn = n0 + n;
+        if (m < g.M && nn < g.N) {
+          d2 v;
+          v.x = smem[(2 * mp) * LDC + n];
+          v.y = smem[(2 * mp + 1) * LDC + n];
+          *reinterpret_cast<d2*>(CT + (int64_t)nn * g.ldct + m) = v;
+        }
       }
     }
     __syncthreads();
@@ -305,10 +323,24 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     const char* e = getenv("WV_GEMM_OCC");
     occ = (e && atoi(e) == 1) ? 1 : 2;
   }
+  if (a.tout != 0) {
+    // transposed outputs exist for the two products that feed K-strided operands downstream
+    if (a.tout == 1 && a_kc && !b_kc) {
+      if (bn == 128) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 128, 2, 1>), g, blk, 0, st, a);
+      else hipLaunchKernelGGL((gemm_f64_kernel<true, false, 64, 2, 1>), g, blk, 0, st, a);
+    } else if (a.tout == 2 && !a_kc && !b_kc) {
+      if (bn == 128) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 2>), g, blk, 0, st, a);
+      else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 64, 2, 2>), g, blk, 0, st, a);
+    } else {
+      fprintf(stderr, "launch_gemm: unsupported transposed-output variant\n");
+      abort();
+    }
+    return;
+  }
 #define WV_LAUNCH(AK, BK, BNN)                                                  \
   do {                                                                          \
-    if (occ == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 1>), g, blk, 0, st, a); \
-    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 2>), g, blk, 0, st, a);          \
+    if (occ == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 1, 0>), g, blk, 0, st, a); \
+    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 2, 0>), g, blk, 0, st, a);          \
   } while (0)
   if (bn == 128) {
     if (a_kc && b_kc) WV_LAUNCH(true, true, 128);
