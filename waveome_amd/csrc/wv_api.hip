@@ -275,7 +275,7 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_status) hipHostFree(g.h_status);
   }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
-                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus};
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part};
   for (void* q : ptrs)
     if (q) hipFree(q);
   delete h;
@@ -344,6 +344,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
             alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&
             alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
             alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
+  if (ok && Np <= 2048) ok = alloc((void**)&p.dsolve_part, sizeof(double) * (Np / 64) * Np * max_batch);
   if (!ok) {
     set_error("device allocation failed (workspace for max_batch fits does not fit in HBM)");
     return WV_E_OOM;

@@ -245,6 +245,73 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const double* __restrict__ 
   if (wave == 0) aall[(int64_t)b * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// One pass over M for both solves (Npad <= 2048): a wave owns 16 consecutive rows; for row i it
+// keeps the row in registers, forms z_i = M[i,:] r (wave reduction) and immediately accumulates
+// z_i M[i,:] into its slice of alpha = M' z.  Per-workgroup partial alphas (rows of a 64-row block)
+// are summed across row blocks by alpha_reduce_kernel in a fixed order (deterministic).
+constexpr int TRMV_MAXC = 16;  // 128-column chunks per row
+
+__global__ __launch_bounds__(256) void trmv_fused_kernel(const double* __restrict__ Mall,
+                                                         const double* __restrict__ rall,
+                                                         double* __restrict__ zall,
+                                                         double* __restrict__ part, int64_t Npad,
+                                                         int nrb, int slot0) {
+  extern __shared__ __attribute__((aligned(16))) double red[];  // [4][Npad]
+  const int b = slot0 + blockIdx.y, rb = blockIdx.x;
+  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const double* r = rall + (int64_t)b * Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = (rb * 64 + 64 + 127) / 128;  // chunks that can hold non-zeros for this row block
+  double2 rvec[TRMV_MAXC], acc[TRMV_MAXC];
+#pragma unroll
+  for (int c = 0; c < TRMV_MAXC; ++c) {
+    acc[c] = make_double2(0.0, 0.0);
+    rvec[c] = (c < nch && 128 * c + 2 * lane < Npad) ? *reinterpret_cast<const double2*>(r + 128 * c + 2 * lane)
+                                                       : make_double2(0.0, 0.0);
+  }
+  for (int rr = 0; rr < 16; ++rr) {
+    const int64_t i = (int64_t)rb * 64 + wave * 16 + rr;
+    const double* row = M + i * Npad;
+    double2 rv[TRMV_MAXC];
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < TRMV_MAXC; ++c) {
+      // columns beyond i are zero in M (strictly upper part), so whole chunks can be skipped
+      rv[c] = (128 * c <= i && 128 * c + 2 * lane < Npad) ? *reinterpret_cast<const double2*>(row + 128 * c + 2 * lane)
+                                                           : make_double2(0.0, 0.0);
+      s += rv[c].x * rvec[c].x + rv[c].y * rvec[c].y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) zall[(int64_t)b * Npad + i] = s;
+#pragma unroll
+    for (int c = 0; c < TRMV_MAXC; ++c) {
+      acc[c].x += s * rv[c].x;
+      acc[c].y += s * rv[c].y;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < TRMV_MAXC; ++c)
+    if (c < nch && 128 * c + 2 * lane < Npad)
+      *reinterpret_cast<double2*>(red + (int64_t)wave * Npad + 128 * c + 2 * lane) = acc[c];
+  __syncthreads();
+  double* out = part + ((int64_t)b * nrb + rb) * Npad;
+  const int ncol = min(nch * 128, (int)Npad);
+  for (int j = threadIdx.x; j < ncol; j += 256)
+    out[j] = red[j] + red[Npad + j] + red[2 * Npad + j] + red[3 * Npad + j];
+}
+
+__global__ void alpha_reduce_kernel(const double* __restrict__ part, double* __restrict__ aall, int64_t Npad,
+                                    int nrb, int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Npad) return;
+  double s = 0.0;
+  // row block rb holds columns < 128 * ceil((64 rb + 64) / 128); column j first appears in block j / 64
+  for (int rb = (int)(j / 64); rb < nrb; ++rb) s += part[((int64_t)b * nrb + rb) * Npad + j];
+  aall[(int64_t)b * Npad + j] = s;
+}
+
 // generic lower-triangular products on any N x N buffer: out = T in (trans = false) or T' in
 void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* in, double* out, int slot0,
                  int nb, bool trans) {
@@ -256,6 +323,16 @@ void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* i
 
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha) {
   p.timer.begin(st, ST_SOLVE);
+  if (need_alpha && p.dsolve_part && p.Npad <= 128 * TRMV_MAXC) {
+    const int nrb = (int)(p.Npad / 64);
+    hipLaunchKernelGGL(trmv_fused_kernel, dim3(nrb, nb), dim3(256), (size_t)4 * p.Npad * sizeof(double), st, p.Mbuf,
+                       p.dr, p.dz, p.dsolve_part, p.Npad, nrb, slot0);
+    hipLaunchKernelGGL(alpha_reduce_kernel, dim3((unsigned)((p.Npad + 255) / 256), nb), dim3(256), 0, st,
+                       p.dsolve_part, p.dalpha, p.Npad, nrb, slot0);
+    p.timer.end(st);
+    p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + 1) / 2.0 + 2.0 * nrb * p.Npad / 2.0));
+    return;
+  }
   hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
                      p.dz, p.Npad, slot0);
   if (need_alpha)

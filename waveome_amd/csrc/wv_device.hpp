@@ -135,6 +135,7 @@ struct Problem {
   DevSpec* dspec = nullptr;
   double *Kbuf = nullptr, *Mbuf = nullptr, *MTbuf = nullptr, *Pbuf = nullptr;
   double *dtheta = nullptr, *dr = nullptr, *dz = nullptr, *dalpha = nullptr;
+  double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
   double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials
   double *dout = nullptr;      // [max_batch][out_stride]
