@@ -581,7 +581,7 @@ void lauum(Problem& p, hipStream_t st, int slot0, int nb) {
   a.B = p.Mbuf + (int64_t)slot0 * mat;  // B(n, l) = M[l][n]
   a.C = p.Kbuf + (int64_t)slot0 * mat;
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
-  a.tri = 1; a.tri_off = 0;
+  a.tri = 1; a.tri_off = 0; a.tag = 1;
   p.timer.begin(st, ST_LAUUM);
   launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
   p.timer.end(st);
