@@ -79,6 +79,7 @@ struct GemmArgs {
   int32_t ldct, tout;
   int32_t tag;         // 1: launch the separately named instantiation (K_y^-1 = M'M)
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
+  int32_t latin;
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
 };
 

@@ -115,10 +115,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   // longest contraction first: ranges trimmed from above (khi_mode) grow with the tile index
   if (g.khi_mode && !g.tri) tile = tiles - 1 - tile;
   // When the contraction length depends on the tile COLUMN it repeats with period tiles_n in launch
-  // order; workgroups appear to be dealt to shader engines round-robin, so a power-of-two period
-  // leaves some engines with only short tiles (PMC: 1.3 instead of 2 resident waves per SIMD).
-  // Rotating the order by a different amount for every matrix spreads all lengths over all engines.
-  if ((g.khi_mode == 2 || g.klo_mode == 2) && !g.tri) tile = (tile + 3 * (b >> 3) + (b & 7)) % tiles;
+  // order; workgroups appear to be dealt to an XCD's shader engines in order, round-robin, so a
+  // power-of-two period leaves some engines with only short tiles and the in-order dealer stalls on
+  // the full ones (PMC: 1.3 instead of 2 resident waves per SIMD).  Default fix: the Latin-square skew
+  // below (latin = 1); latin = 0 is the older per-matrix rotation of the launch order.
+  if ((g.khi_mode == 2 || g.klo_mode == 2) && !g.tri && g.latin != 1) tile = (tile + 3 * (b >> 3) + (b & 7)) % tiles;
   int tm, tn;
   if (g.tri) {
     // (rotating lower-only products or row-dependent lengths the same way measured no gain)
@@ -134,6 +135,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   } else {
     tm = tile / g.tiles_n;
     tn = tile % g.tiles_n;
+    // column-dependent lengths: skew every tile row by its index (Latin square) so that any
+    // power-of-two stride through the launch order meets every length equally often
+    if (g.latin && (g.khi_mode == 2 || g.klo_mode == 2)) tn = (tn + tm) % g.tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -309,6 +313,11 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     tiles = 0;
     for (int tm = 0; tm < a.tiles_m; ++tm)
       tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / bn + 1));
+  }
+  {
+    static int lat = -1;
+    if (lat < 0) { const char* e = getenv("WV_GEMM_LATIN"); lat = e ? atoi(e) : 1; }
+    a.latin = lat;  // 0: per-matrix rotation, 1: Latin-square skew only, 2: both
   }
   a.tiles_live = tiles;
   {
