@@ -417,7 +417,7 @@ def test_iterated_penalization_factor(ctx):
 
 
 # ---------------------------------------------------------------- edge cases and the other BASELINE configs
-@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129, 200])
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129, 200, 1000, 2049])  # 2049 -> Npad 2112: two-kernel solve path
 def test_ragged_and_tiny_sizes(ctx, N):
     """Empty-ish and ragged inputs: N below / at / just above the 64-row block, odd N."""
     from waveome_amd.engine import Problem

@@ -300,7 +300,7 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     const char* e = getenv("WV_GEMM2_MIN");
     v2_min = e ? atoi(e) : 0;  // off by default: no faster on the triangular forms
   }
-  if (bn == 256 || (bn == 128 && v2_min > 0 && a_in.M >= v2_min && a_in.N >= 128)) {
+  if (a_in.tout == 0 && (bn == 256 || (bn == 128 && v2_min > 0 && a_in.M >= v2_min && a_in.N >= 128))) {
     launch_gemm2(st, a_in, a_kc, b_kc);
     return;
   }
