@@ -558,3 +558,39 @@ def test_config_c5_size_properties_n16384(ctx):
     sub.close()
     ref = o.lml(ms.to_dict(), th, X[:2048], y[:2048])
     assert s2[0] == 0 and abs(l2[0] - ref) <= 1e-10 * abs(ref)
+
+
+def test_kernel_sweep_columns_by_structures(ctx):
+    """Y-columns x candidate kernel structures (north star / config C4 in miniature): every pair's loss and
+    BIC against SciPy L-BFGS-B on the oracle objective."""
+    import pandas as pd
+
+    from waveome_amd.model_search import GPSearch
+
+    rng = np.random.default_rng(12)
+    N = 90
+    Xd = pd.DataFrame({"unit": rng.integers(0, 6, N).astype(float), "t": rng.uniform(0, 6, N), "z": rng.normal(size=N)})
+    Yd = pd.DataFrame({f"m{p}": np.sin((1 + 0.5 * p) * Xd["t"]) + 0.3 * Xd["z"] * p + 0.1 * (Xd["unit"] - 2.5)
+                       + 0.15 * rng.normal(size=N) for p in range(3)})
+    gps = GPSearch(Xd, Yd, unit_col="unit")
+    structures = {
+        "se": K.Categorical(active_dims=[0]) + K.SquaredExponential(active_dims=[1]) + K.SquaredExponential(active_dims=[2]),
+        "m32": K.Categorical(active_dims=[0]) + K.Matern32(active_dims=[1]) + K.Matern32(active_dims=[2]),
+        "lin": K.Categorical(active_dims=[0]) + K.Lin(active_dims=[1]) + K.Lin(active_dims=[2]),
+    }
+    table = gps.kernel_sweep(structures, context=ctx)
+    assert table.shape[0] == 9 and set(table.index.get_level_values("structure")) == set(structures)
+    X = gps.X.to_numpy()
+    for (feat, nm), row in table.iterrows():
+        mod = gps.sweep_models[(feat, nm)]
+        d = mod._spec().to_dict()
+        y = gps.Y[feat].to_numpy()
+        # same start as the sweep used (GPflow defaults)
+        d0 = ModelSpec(structures[nm], 3, mean_function=K.ConstantMean()).to_dict()
+        ref = o.fit(d0, X, y)
+        assert row["loss"] == pytest.approx(ref["loss"], rel=1e-5, abs=1e-5), (feat, nm)
+        k_count = sum(q["trainable"] for q in d["params"]) + 2
+        assert row["bic"] == pytest.approx(round(2 * k_count + 2 * ref["loss"], 2), abs=0.02)
+    # the smooth periodic-ish signal should prefer a stationary kernel over the linear one
+    best = table.groupby("output")["bic"].idxmin()
+    assert all(s != "lin" for (_, s) in best.values)

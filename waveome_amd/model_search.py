@@ -225,6 +225,93 @@ class GPSearch:
         return None
 
 
+    # ------------------------------------------------------------------------------------------
+    def kernel_sweep(self, kernels, mean_function=None, penalization_factor=0.0, num_restart=0,
+                     random_seed=None, num_opt_iter=50000, max_batch=None, context=None, keep_models=True):
+        """Fit every (output column x candidate kernel structure) pair and tabulate the information
+        criterion - the "Y-columns x candidate kernel structures" sweep of the north star (config C4:
+        512 outputs x 6 kernels).  Each pair is what the reference's `kernel_test` evaluates for one
+        candidate (model_search.py:2239-2334: PSVGP with penalization_factor = 0, then
+        `calc_bic(log_posterior_density, n, k)`), except that the fit is the L-BFGS-B path of this build
+        (the reference's kernel_test defaults to its Adam / natural-gradient branch, which is out of scope).
+
+        kernels: dict name -> kernel (or a list; names default to the printed structure).
+        Tasks are sharded over ranks when torch.distributed is initialised (cost ~ parameters per
+        structure), one Problem per structure per rank.  Returns a DataFrame indexed by
+        (output, structure) with loss, lml, bic, nit, nfev, status; `self.sweep_models[(output, name)]`
+        holds the fitted PSVGP objects when keep_models."""
+        from .utilities import print_kernel_names
+
+        if not isinstance(kernels, dict):
+            kernels = {str(print_kernel_names(k, with_idx=True)): k for k in kernels}
+        names = list(kernels)
+        if mean_function is None:
+            mean_function = K.ConstantMean()
+        Xn = self.X.to_numpy(dtype=np.float64)
+        Yn = self.Y.to_numpy(dtype=np.float64)
+        N, P, S = Xn.shape[0], Yn.shape[1], len(names)
+        ctx = context or default_context()
+        opts = lbfgs_opts(maxiter=num_opt_iter)
+        n_starts = max(1, int(num_restart))
+        rng = np.random.RandomState(random_seed)
+        templates, specs = [], []
+        for nm in names:
+            t = PSVGP(Xn, Yn[:, :1], mean_function=mean_function, kernel=kernels[nm],
+                      penalized_options={"penalization_factor": penalization_factor}, context=ctx)
+            templates.append(t)
+            specs.append(t._spec())
+        width = max(sp.n_trainable for sp in specs)
+        # task list: structure-major so that a rank's tasks of one structure share a Problem
+        task_s = np.repeat(np.arange(S), P * n_starts)
+        task_p = np.tile(np.repeat(np.arange(P), n_starts), S)
+        starts = []
+        for sp in specs:
+            u0 = sp.unconstrain()
+            blk = np.tile(u0, (P * n_starts, 1))
+            if num_restart > 0:
+                blk = rng.normal(size=blk.shape)
+            starts.append(blk)
+        costs = np.array([specs[s_].n_trainable for s_ in task_s], dtype=np.float64)
+
+        def fit_shard(ids):
+            out = np.full((len(ids), 5 + width), np.nan)
+            for s_ in np.unique(task_s[ids]):
+                sel = np.nonzero(task_s[ids] == s_)[0]
+                sp = specs[s_]
+                mb = max_batch or min(len(sel), _default_batch(N))
+                prob = Problem(ctx, Xn, Yn, sp, max_batch=max(1, mb))
+                local = ids[sel] - s_ * P * n_starts  # row inside this structure's start block
+                res = prob.fit(task_p[ids[sel]].astype(np.int32), starts[s_][local], opts)
+                prob.close()
+                out[sel, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
+                out[sel, 5:5 + sp.n_trainable] = res["u"]
+            return out
+
+        rank, world = parallel.dist_info()
+        n_tasks = len(task_s)
+        rec = parallel.sharded_map(n_tasks, fit_shard, costs=costs) if world > 1 else fit_shard(np.arange(n_tasks))
+        rows, self.sweep_models = [], {}
+        for s_, nm in enumerate(names):
+            sp = specs[s_]
+            k_count = sum(1 for q in sp.param_objs if q.trainable) + 2  # + q_mu, q_sqrt (utilities.py:94-95)
+            for p, feat in enumerate(self.out_names):
+                blk = rec[(s_ * P + p) * n_starts:(s_ * P + p + 1) * n_starts]
+                best = blk[np.argmin(blk[:, 0])]
+                loglik = -best[0]  # log posterior density = LML + log prior = -training loss
+                rows.append({"output": feat, "structure": nm, "loss": best[0], "lml": best[1],
+                             "bic": round(2 * k_count - 2 * loglik, 2), "nit": int(best[2]), "nfev": int(best[3]),
+                             "status": int(best[4])})
+                if keep_models:
+                    mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=mean_function, kernel=kernels[nm],
+                                penalized_options={"penalization_factor": penalization_factor}, context=ctx)
+                    ms_ = mod._spec()
+                    ms_.assign_theta(ms_.constrain(best[5:5 + sp.n_trainable]))
+                    mod.fit_result = rows[-1]
+                    self.sweep_models[(feat, nm)] = mod
+        self.sweep_results = pd.DataFrame(rows).set_index(["output", "structure"])
+        return self.sweep_results
+
+
 def _default_batch(n: int) -> int:
     """Fits in flight per GPU: two N x N float64 matrices per slot, capped at ~64 GiB of HBM."""
     npad = (n + 63) // 64 * 64
