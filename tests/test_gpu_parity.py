@@ -594,3 +594,32 @@ def test_kernel_sweep_columns_by_structures(ctx):
     # the smooth periodic-ish signal should prefer a stationary kernel over the linear one
     best = table.groupby("output")["bic"].idxmin()
     assert all(s != "lin" for (_, s) in best.values)
+
+
+def test_results_do_not_depend_on_batch_composition(ctx):
+    """A task's loss / gradient / fitted parameters are bit-identical whatever slot, batch size or group
+    layout it runs in - which is what makes 1-GPU and k-GPU runs of the same task list agree exactly
+    (test-plan item 6; reductions use fixed orders, no float atomics)."""
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(41, 300, P=6)
+    ms = _with_priors(ModelSpec(_composite(), 4, mean_function=K.ConstantMean()))
+    rng = np.random.default_rng(2)
+    U = np.stack([ms.unconstrain() + 0.2 * rng.normal(size=ms.n_trainable) for _ in range(6)])
+    cols = np.arange(6, dtype=np.int32)
+    big = Problem(ctx, X, Y, ms, max_batch=16)
+    l_all, g_all, _ = big.value_grad(cols, U)
+    l_rev, g_rev, _ = big.value_grad(cols[::-1].copy(), U[::-1].copy())
+    np.testing.assert_array_equal(l_all, l_rev[::-1])
+    np.testing.assert_array_equal(g_all, g_rev[::-1])
+    small = Problem(ctx, X, Y, ms, max_batch=1)
+    for t in (0, 3, 5):
+        l1, g1, _ = small.value_grad(cols[t:t + 1], U[t:t + 1])
+        assert l1[0] == l_all[t]
+        np.testing.assert_array_equal(g1[0], g_all[t])
+    fit_big = big.fit(cols, U, lbfgs_opts(maxiter=25))
+    fit_small = small.fit(cols, U, lbfgs_opts(maxiter=25))
+    np.testing.assert_array_equal(fit_big["u"], fit_small["u"])
+    np.testing.assert_array_equal(fit_big["loss"], fit_small["loss"])
+    big.close()
+    small.close()
