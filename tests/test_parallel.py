@@ -29,6 +29,9 @@ out = parallel.sharded_map(11, fn, costs=costs)
 mine = parallel.shard_tasks(11, rank, world, costs)
 np.save(os.environ["WV_OUT"] + f".{rank}.npy", out)
 np.save(os.environ["WV_OUT"] + f".ids{rank}.npy", mine)
+# fewer tasks than ranks (a search step with a single candidate): the idle rank still joins the gather
+one = parallel.sharded_map(1, fn, width=3)
+np.save(os.environ["WV_OUT"] + f".one{rank}.npy", one)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -72,5 +75,7 @@ def test_world_size_two_gloo_matches_single_process(tmp_path):
     ids = np.arange(11)
     ref = np.column_stack([[float(np.dot(Y[i], X[:, 0])) for i in ids], [Y[i].sum() * (i + 1) for i in ids], ids.astype(float)])
     np.testing.assert_array_equal(r0, ref)  # bit-identical to the 1-process result
+    np.testing.assert_array_equal(np.load(out + ".one0.npy"), ref[:1])
+    np.testing.assert_array_equal(np.load(out + ".one1.npy"), ref[:1])
     i0, i1 = np.load(out + ".ids0.npy"), np.load(out + ".ids1.npy")
     assert sorted(np.concatenate([i0, i1]).tolist()) == list(range(11)) and abs(len(i0) - len(i1)) <= 1

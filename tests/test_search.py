@@ -1,0 +1,230 @@
+"""Compositional kernel search: candidate generation and control flow on the CPU,
+and the GPU-scored search against the same search scored by the CPU oracle.
+
+The reference holds no tests for `run_search` / `full_kernel_search`; the expected candidate names below
+are derived by hand from waveome/model_search.py:2347-2664 (naming `k.name + str(k.active_dims)`, the
+`base_name < k_info` ordering rule, the categorical / two-way-interaction skips)."""
+import copy
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import gp_oracle as O  # noqa: E402
+from waveome_amd import kernel_search as ks  # noqa: E402
+from waveome_amd import kernels as K  # noqa: E402
+from waveome_amd.spec import ModelSpec  # noqa: E402
+from waveome_amd.utilities import check_if_model_exists  # noqa: E402
+
+
+def default_kernels():
+    return [K.SquaredExponential(), K.Matern12(), K.Lin(), K.Periodic(K.SquaredExponential())]
+
+
+def test_check_if_model_exists_ignores_term_and_factor_order():
+    models = ["lin[1]+squared_exponential[0]", "categorical[2]*lin[0]"]
+    assert check_if_model_exists("squared_exponential[0]+lin[1]", models)
+    assert check_if_model_exists("lin[0]*categorical[2]", models)
+    assert not check_if_model_exists("lin[1]", models)
+    assert not check_if_model_exists("lin[1]+squared_exponential[1]", models)
+
+
+def test_depth1_candidates():
+    c = ks.loc_kernel_candidates(3, default_kernels(), cat_vars=[2], depth=1)
+    assert list(c) == ["squared_exponential[0]", "matern12[0]", "lin[0]", "periodic[0]", "constant",
+                       "squared_exponential[1]", "matern12[1]", "lin[1]", "periodic[1]", "categorical[2]"]
+    const = c["constant"]
+    assert const.variance.value == 1e-6 and not const.variance.trainable
+    assert c["periodic[1]"].active_dims == [1] and c["lin[1]"].active_dims == [1]
+    # the caller's kernel list is never touched
+    kl = default_kernels()
+    ks.loc_kernel_candidates(3, kl, cat_vars=[2], depth=1)
+    assert all(k.active_dims in (None, [0]) for k in kl)
+
+
+def test_sum_and_product_candidates():
+    kl = default_kernels()
+    d1 = ks.loc_kernel_candidates(3, kl, cat_vars=[2], depth=1)
+    base = copy.deepcopy(d1["squared_exponential[0]"])
+    base.variance.assign(3.0)
+    base.lengthscales.assign(0.2)
+    s = ks.loc_kernel_candidates(3, kl, base_kern=base, base_name="squared_exponential[0]", cat_vars=[2], depth=2,
+                                 operation="sum", prev_models=list(d1))
+    assert list(s) == ["matern12[0]+squared_exponential[0]", "lin[0]+squared_exponential[0]",
+                       "periodic[0]+squared_exponential[0]", "squared_exponential[0]+squared_exponential[1]",
+                       "matern12[1]+squared_exponential[0]", "lin[1]+squared_exponential[0]",
+                       "periodic[1]+squared_exponential[0]", "categorical[2]+squared_exponential[0]"]
+    # the base restarts from 1.0 (model_search.py:2420-2421) and kernel order follows the name
+    cand = s["lin[1]+squared_exponential[0]"]
+    assert [k.name for k in cand.kernels] == ["lin", "squared_exponential"]
+    assert cand.kernels[1].variance.value == 1.0 and cand.kernels[1].lengthscales.value == 1.0
+    p = ks.loc_kernel_candidates(3, kl, base_kern=base, base_name="squared_exponential[0]", cat_vars=[2], depth=2,
+                                 operation="product", prev_models=list(d1) + list(s))
+    assert "categorical[2]*squared_exponential[0]" in p and "lin[1]*squared_exponential[0]" in p
+    # the new factor's variance is frozen at 1 (model_search.py:2469-2472), periodic through its base kernel
+    prod = p["periodic[1]*squared_exponential[0]"]
+    assert not prod.kernels[0].base_kernel.variance.trainable and prod.kernels[1].variance.trainable
+    # a product is not multiplied again, a categorical feature already in the base is skipped
+    assert ks.loc_kernel_candidates(3, kl, base_kern=prod, base_name="periodic[1]*squared_exponential[0]",
+                                    cat_vars=[2], depth=3, operation="product") == {}
+    cat = d1["categorical[2]"]
+    s2 = ks.loc_kernel_candidates(3, kl, base_kern=cat, base_name="categorical[2]", cat_vars=[2], depth=2,
+                                  operation="sum", prev_models=list(d1))
+    assert all("categorical[2]+" in n for n in s2) and len(s2) == 8
+    # models fitted before are not generated again
+    again = ks.loc_kernel_candidates(3, kl, base_kern=base, base_name="squared_exponential[0]", cat_vars=[2],
+                                     depth=2, operation="sum", prev_models=list(d1) + list(s))
+    assert again == {}
+
+
+def test_split_product_candidates_keep_names_and_kernels_aligned():
+    kl = [K.SquaredExponential(), K.Lin()]
+    base = K.Sum([K.Categorical(active_dims=[2]), K.SquaredExponential(active_dims=[0])])
+    c = ks.loc_kernel_candidates(3, kl, base_kern=base, base_name="categorical[2]+squared_exponential[0]",
+                                 cat_vars=[2], depth=3, operation="split_product", prev_models=[])
+    assert "categorical[2]*lin[1]+squared_exponential[0]" in c
+    assert "categorical[2]+lin[1]*squared_exponential[0]" in c
+    assert "categorical[2]+categorical[2]*squared_exponential[0]" in c
+    assert not any(n.startswith("categorical[2]*categorical[2]") for n in c)
+    for name, kern in c.items():
+        parts = name.split("+")
+        assert len(parts) == len(kern.kernels)
+        for part, comp in zip(parts, kern.kernels):
+            got = "*".join(ks.kernel_info(f) for f in comp.kernels) if comp.name == "product" else ks.kernel_info(comp)
+            assert got == part
+
+
+def test_prune_candidates():
+    k = K.Sum([K.Product([K.Categorical(active_dims=[2]), K.Lin(active_dims=[1])]),
+               K.SquaredExponential(active_dims=[0])])
+    k.kernels[1].lengthscales.assign(0.3)
+    c = ks.prune_candidates("categorical[2]*lin[1]+squared_exponential[0]", k, existing=["lin[1]"])
+    assert set(c) == {"categorical[2]+squared_exponential[0]", "lin[1]+squared_exponential[0]",
+                      "categorical[2]*lin[1]"}
+    assert c["lin[1]+squared_exponential[0]"].kernels[1].lengthscales.value == 1.0  # reset (:2857-2858)
+    # nothing to prune in a single base kernel; a lone product is split into its factors
+    assert ks.prune_candidates("lin[1]", K.Lin(active_dims=[1]), []) == {}
+    lone = ks.prune_candidates("categorical[2]*lin[1]", k.kernels[0], existing=["lin[1]"])
+    assert list(lone) == ["categorical[2]"]
+
+
+def _drive(table, **kw):
+    """Run one search generator against a table name -> bic (missing names: 1000)."""
+    g = ks.full_kernel_search_steps(2, [K.SquaredExponential(), K.Lin()], **kw)
+    asked = []
+    try:
+        req = next(g)
+        while True:
+            asked.append(list(req))
+            req = g.send({n: {"bic": table.get(n, 1000.0)} for n in req})
+    except StopIteration as e:
+        return e.value, asked
+
+
+def test_search_stops_on_constant_and_on_no_improvement():
+    res, asked = _drive({"constant": 1.0})
+    assert res["best_model"] == "constant" and len(asked) == 1
+    # depth 2 does not beat depth 1 -> stop after (pruning) depth 2
+    res, asked = _drive({"lin[0]": 10.0, "lin[0]+squared_exponential[1]": 11.0})
+    assert res["best_model"] == "lin[0]" and res["depth_reached"] == 2
+    # keep_top_k: only candidates within metric_diff of the level's best are expanded
+    res, asked = _drive({"lin[0]": 10.0, "lin[1]": 12.0, "squared_exponential[0]": 30.0,
+                         "lin[0]+lin[1]": 5.0}, max_depth=2)
+    assert res["best_model"] == "lin[0]+lin[1]"
+    depth2 = asked[1]
+    assert any(n.startswith("lin[0]+") or n.endswith("+lin[0]") for n in depth2)
+    assert not any("squared_exponential[0]*" in n and "lin" not in n for n in depth2)
+    assert all(("lin[0]" in n) or ("lin[1]" in n) for n in depth2)
+
+
+def test_search_prune_inserts_only_improvements():
+    table = {"lin[0]": 10.0, "lin[0]+squared_exponential[1]": 8.0,
+             "lin[0]*squared_exponential[0]+squared_exponential[1]": 7.0,
+             # pruning the product at depth 3 offers lin[0]+squared_exponential[1] (exists),
+             # squared_exponential[0]+squared_exponential[1] and lin[0]*squared_exponential[0]
+             "squared_exponential[0]+squared_exponential[1]": 6.5}
+    res, asked = _drive(table, max_depth=3, keep_only_best=False)
+    assert res["best_model"] == "squared_exponential[0]+squared_exponential[1]"
+    e = res["models"]["squared_exponential[0]+squared_exponential[1]"]
+    assert e["parent"] == "lin[0]*squared_exponential[0]+squared_exponential[1]" and e["depth"] == 3
+    # pruned structures that do not beat the level's best are not recorded
+    kids = [v for v in res["models"].values() if v["parent"] == "lin[0]*squared_exponential[0]+squared_exponential[1]"]
+    assert len(kids) == 1
+
+
+class OracleScorer:
+    """CPU stand-in for kernel_search.GpuScorer: the same scoring rule on SciPy fits of the oracle."""
+
+    def __init__(self, X, Y):
+        self.X, self.Y, self.cache = X, Y, {}
+        self.n_fits = 0
+
+    def __call__(self, tasks):
+        out = []
+        for col, kern in tasks:
+            spec = ModelSpec(kern, self.X.shape[1], K.GaussianLikelihood(), K.ConstantMean())
+            key = (col, ks.structure_signature(spec))
+            if key not in self.cache:
+                r = O.fit(spec.to_dict(), self.X, self.Y[:, col])
+                k_count = sum(1 for q in spec.param_objs if q.trainable) + 2
+                self.cache[key] = {"bic": round(2 * k_count + 2 * r["loss"], 2), "loss": r["loss"], "lml": r["lml"],
+                                   "nit": r["nit"], "nfev": r["nfev"], "status": r["status"], "u": r["u"]}
+                self.n_fits += 1
+            out.append(self.cache[key])
+        return out
+
+
+def search_data(n=48, seed=3):
+    rng = np.random.default_rng(seed)
+    x0 = rng.normal(size=n)
+    x1 = rng.normal(size=n)
+    g = (np.arange(n) % 3).astype(float)
+    X = pd.DataFrame({"t": x0, "dose": x1, "grp": g})
+    Y = pd.DataFrame({"lin_dose": 1.5 * x1 + 0.2 * rng.normal(size=n),
+                      "smooth_t": np.sin(2.0 * x0) + 0.15 * rng.normal(size=n),
+                      "noise": rng.normal(size=n)})
+    return X, Y
+
+
+def test_oracle_scored_search_recovers_structure():
+    from waveome_amd.model_search import GPSearch
+
+    X, Y = search_data()
+    gps = GPSearch(X, Y, categorical_vars=["grp"])
+    Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+    res = ks.run_searches(range(3), 3, [K.SquaredExponential(), K.Lin()], OracleScorer(Xn, Yn), cat_vars=[2],
+                          max_depth=2)
+    assert "lin[1]" in res[0]["best_model"]
+    assert "[0]" in res[1]["best_model"] and "lin[1]" not in res[1]["best_model"]
+    assert res[2]["best_model"] == "constant"
+
+
+@pytest.mark.gpu
+def test_gpu_search_matches_oracle_scored_search():
+    from waveome_amd.model_search import GPSearch
+
+    X, Y = search_data()
+    kl = [K.SquaredExponential(), K.Lin()]
+    gps = GPSearch(X, Y, categorical_vars=["grp"])
+    gps.run_search(kernels=kl, max_depth=3, keep_only_best=False)
+    Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+    ref = ks.run_searches(range(3), 3, kl, OracleScorer(Xn, Yn), cat_vars=[2], max_depth=3, keep_only_best=False)
+    for p, feat in enumerate(gps.out_names):
+        got = gps.search_info[feat]
+        assert got["best_model"] == ref[p]["best_model"]
+        assert set(got["models"]) == set(ref[p]["models"])
+        bics = np.array([[got["models"][n]["bic"], ref[p]["models"][n]["bic"]] for n in got["models"]])
+        close = np.abs(bics[:, 0] - bics[:, 1]) <= 0.02 + 1e-6 * np.abs(bics[:, 1])
+        assert close.mean() >= 0.9, bics[~close]
+        assert abs(got["models"][got["best_model"]]["bic"] - ref[p]["models"][ref[p]["best_model"]]["bic"]) <= 0.02
+        m = gps.models[feat]
+        assert m.kernel_name == got["best_model"]
+        # the stored model carries the fitted parameters: its objective is the recorded one
+        assert abs(m.training_loss() - got["models"][got["best_model"]]["fit"]["loss"]) < 1e-6
+        assert len(got["var_exp"]) == (len(m.kernel.kernels) if m.kernel.name == "sum" else 1) + 1
+    assert gps.search_stats["fits"] > 30

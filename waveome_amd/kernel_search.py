@@ -1,0 +1,431 @@
+"""Compositional kernel search on top of the batched GPU fit.
+
+Reference: waveome/model_search.py - `full_kernel_search` (:2987-3273), `loc_kernel_search`
+(:2347-2558), `prod_kernel_creation` (:2561-2664), `check_if_better_metric` (:2667-2681),
+`keep_top_k` (:2684-2710), `prune_best_model2` (:2778-2885), `prune_prod_kernel` (:2888-2984),
+`kernel_test` (:2239-2334); waveome/utilities.py `check_if_model_exists` (:281-307).
+
+Design.  In the reference every output column walks the search tree in its own Ray task and
+calls `kernel_test` (build a model, fit it, score it) once per candidate, one after the other.
+Every candidate starts from the default parameter values (the base kernel's trainable
+parameters are re-assigned 1.0 at :2420-2421 and :2857-2858, new kernels are fresh copies, the
+mean / likelihood are fresh), so a fit depends only on (structure, output column): the
+candidates of one depth level are independent of each other.  Here the per-output search is a
+*generator* that yields the list of candidates it wants scored wherever the reference loops
+over `kernel_test`, and `run_searches` advances the generators of all output columns in lock
+step, pooling their requests: one `Problem` per distinct structure, fitted for all the columns
+that asked for it in one batched call (sharded over ranks when torch.distributed is up).
+
+Deliberate deviations, all in code the reference itself flags as unfinished:
+ * `prod_kernel_creation` re-inserts the *name* of a re-ordered product term at its sorted
+   position but leaves the kernel where it was, so names and `kernel.kernels` disagree later in
+   `prune_best_model2` (its TODO at :2816).  Here the kernel moves with its name.
+ * `prune_prod_kernel` builds `np.array(other_kernel + [piece])[argsort([other_name, piece])]`,
+   which keeps only the first two kernels when `other_kernel` has more than one (:2939-2944).
+   Here all the other components are kept.
+ * a depth level that yields no new candidate ends the search (the reference raises on `min([])`).
+ * candidates whose fit fails (non-finite objective) are dropped, as the reference's
+   `try / except: None` around `kernel_test` does.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import kernels as K
+from . import parallel
+from .spec import ModelSpec
+from .utilities import calc_bic, check_if_model_exists
+
+
+# ---------------------------------------------------------------------------------------------
+# names and candidate generation (host only)
+# ---------------------------------------------------------------------------------------------
+def kernel_info(k) -> str:
+    """`k.name + str(k.active_dims)` (model_search.py:2402), "constant" for the static kernel."""
+    if k.name == "constant":
+        return k.name
+    return k.name + "[" + " ".join(str(int(d)) for d in k.active_dims) + "]"
+
+
+def set_feature_kernels(f: int, kern_list: Sequence, cat_vars: Sequence[int]) -> List:
+    """model_search.py:2337-2344."""
+    if f in cat_vars:
+        return [K.Categorical(active_dims=[f])]
+    k_list = list(kern_list)
+    for k_ in k_list:
+        k_.active_dims = [int(f)]
+    return k_list
+
+
+def _reset_trainable(kernel):
+    for p in kernel.trainable_parameters:
+        p.assign(1.0)
+
+
+def _freeze_variance(k):
+    try:
+        K.set_trainable(k.variance, False)
+    except AttributeError:
+        K.set_trainable(k.base_kernel.variance, False)
+
+
+def prod_kernel_candidates(base_kernel, base_name: str, new_kernel, prev_models: Iterable[str]) -> Dict[str, object]:
+    """Multiply each additive component of `base_kernel` by `new_kernel` (model_search.py:2561-2664)."""
+    out = {}
+    new_info = kernel_info(new_kernel)
+    for feat in range(len(base_kernel.kernels)):
+        temp_kernel = copy.deepcopy(base_kernel)
+        temp_name = base_name.split("+")
+        if "categorical[" + str(new_kernel.active_dims[0]) + "]" in temp_name[feat]:
+            continue
+        if "*" in temp_name[feat]:  # two-way interactions only
+            continue
+        kerns = list(temp_kernel.kernels)
+        if temp_name[feat] < new_info:
+            temp_name[feat] = temp_name[feat] + "*" + new_info
+            kerns[feat] = K.Product([kerns[feat], copy.deepcopy(new_kernel)])
+        else:
+            prod = K.Product([copy.deepcopy(new_kernel), kerns[feat]])
+            try:
+                new_idx = [new_info < x for x in temp_name].index(True)
+            except ValueError:
+                new_idx = len(temp_name) - 1
+            cur = temp_name.pop(feat)
+            kerns.pop(feat)
+            temp_name.insert(new_idx, new_info + "*" + cur)
+            kerns.insert(new_idx, prod)
+        k_info = "+".join(temp_name)
+        if check_if_model_exists(k_info, list(prev_models)):
+            continue
+        out[k_info] = K.Sum(kerns) if len(kerns) > 1 else kerns[0]
+    return out
+
+
+def loc_kernel_candidates(n_features: int, kern_list: Sequence, base_kern=None, base_name: Optional[str] = None,
+                          cat_vars: Sequence[int] = (), depth: int = 0, operation: str = "sum",
+                          prev_models: Iterable[str] = ()) -> Dict[str, object]:
+    """Candidates of one local search step: name -> kernel (model_search.py:2347-2558 without the fits)."""
+    out: Dict[str, object] = {}
+    prev_models = list(prev_models) if prev_models is not None else []
+    for f in range(n_features):
+        k_list = set_feature_kernels(f, [copy.deepcopy(x) for x in kern_list], cat_vars)
+        if f == 0 and depth == 1:
+            empty_kernel = K.Constant(variance=1e-6)
+            K.set_trainable(empty_kernel.variance, False)
+            k_list = k_list + [empty_kernel]
+        for k in k_list:
+            k_info = kernel_info(k)
+            if base_kern is None:
+                out[k_info] = k
+                continue
+            base_kern_ = copy.deepcopy(base_kern)
+            _reset_trainable(base_kern_)
+            if operation == "sum":
+                if "categorical[" + str(f) + "]" in base_name:
+                    continue
+                if base_name < k_info:
+                    cand, name = K.Sum([base_kern_, k]), base_name + "+" + k_info
+                else:
+                    cand, name = K.Sum([k, base_kern_]), k_info + "+" + base_name
+                if check_if_model_exists(name, prev_models):
+                    continue
+                out[name] = cand
+            elif operation == "product":
+                if "categorical[" + str(f) + "]" in base_name:
+                    continue
+                if "*" in base_name:
+                    continue
+                _freeze_variance(k)
+                if base_name < k_info:
+                    cand, name = K.Product([base_kern_, k]), base_name + "*" + k_info
+                else:
+                    cand, name = K.Product([k, base_kern_]), k_info + "*" + base_name
+                if check_if_model_exists(name, prev_models):
+                    continue
+                out[name] = cand
+            elif operation == "split_product":
+                _freeze_variance(k)
+                out.update(prod_kernel_candidates(base_kern_, base_name, k, prev_models))
+            else:
+                raise ValueError(f"unknown operation {operation!r}")
+    return out
+
+
+def prune_candidates(best_name: str, best_kernel, existing: Iterable[str]) -> Dict[str, object]:
+    """Structures `prune_best_model2` / `prune_prod_kernel` would refit (model_search.py:2778-2984)."""
+    existing = list(existing)
+    out: Dict[str, object] = {}
+    kernel_names = best_name.split("+")
+    if len(kernel_names) <= 1 and "*" not in kernel_names[0]:
+        return out
+    comps = list(best_kernel.kernels) if best_kernel.name == "sum" else [best_kernel]
+    for i in range(len(kernel_names)):
+        others_name = "+".join(x for j, x in enumerate(kernel_names) if j != i)
+        others = [copy.deepcopy(k_) for j, k_ in enumerate(comps) if j != i]
+        if "*" in kernel_names[i]:
+            prod = comps[i]
+            if prod.name != "product":
+                continue
+            parts = kernel_names[i].split("*")
+            for j, piece in enumerate(prod.kernels):
+                if j >= len(parts):
+                    break
+                piece = copy.deepcopy(piece)
+                if others_name == "":
+                    name, cand = parts[j], piece
+                else:
+                    if others_name <= parts[j]:
+                        name, ks = others_name + "+" + parts[j], [copy.deepcopy(o) for o in others] + [piece]
+                    else:
+                        name, ks = parts[j] + "+" + others_name, [piece] + [copy.deepcopy(o) for o in others]
+                    cand = K.Sum(ks)
+                if check_if_model_exists(name, existing):
+                    continue
+                _reset_trainable(cand)
+                out[name] = cand
+            continue
+        cand = K.Sum(others) if len(others) > 1 else others[0]
+        if check_if_model_exists(others_name, existing):
+            continue
+        _reset_trainable(cand)
+        out[others_name] = cand
+    return out
+
+
+def check_if_better_metric(model_dict: dict, depth: int) -> bool:
+    """model_search.py:2667-2681."""
+    prev_vals = [x["bic"] for x in model_dict.values() if x["depth"] == depth - 1]
+    new_vals = [x["bic"] for x in model_dict.values() if x["depth"] == depth]
+    if len(prev_vals) > 0 and len(new_vals) > 0:
+        return bool(min(new_vals) < min(prev_vals))
+    return False
+
+
+def keep_top_k(res_dict: dict, depth: int, metric_diff: float = 6, split: bool = False) -> dict:
+    """Stop expanding candidates more than `metric_diff` above the level's best (model_search.py:2684-2710)."""
+    t = np.log(metric_diff) if split else metric_diff
+    best_bic = min(v["bic"] for v in res_dict.values() if v["depth"] == depth)
+    for v in res_dict.values():
+        if v["depth"] == depth and v["bic"] - best_bic > t:
+            v["try_next"] = False
+    return res_dict
+
+
+# ---------------------------------------------------------------------------------------------
+# the per-output search, as a generator of fit requests
+# ---------------------------------------------------------------------------------------------
+def _entry(kernel, fit, depth, parent):
+    return {"kernel": kernel, "bic": fit["bic"], "depth": depth, "parent": parent, "try_next": True, "fit": fit}
+
+
+def _best_at(search: dict, depth: int):
+    return min((v["bic"], v["depth"], k) for k, v in search.items() if v["depth"] == depth)[2]
+
+
+def full_kernel_search_steps(n_features: int, kern_list: Sequence, cat_vars: Sequence[int] = (), max_depth: int = 5,
+                             keep_all: bool = False, metric_diff: float = 6, early_stopping: bool = True,
+                             prune: bool = True, keep_only_best: bool = True):
+    """Generator form of `full_kernel_search` (model_search.py:2987-3273).
+
+    Yields dict name -> kernel (candidates to score) and expects `.send({name: fit})` back, where
+    fit = {"bic": ..., ...} or None for a failed fit.  Returns (StopIteration.value) the dict the
+    reference returns, without "var_exp" (computed by the caller from the fitted best model)."""
+    search: dict = {}
+    edges: list = []
+
+    def do_prune(d):
+        best_bic, best_name = min((v["bic"], k) for k, v in search.items() if v["depth"] == d)
+        cands = prune_candidates(best_name, search[best_name]["kernel"], search.keys())
+        return best_bic, best_name, cands
+
+    d = 0
+    for d in range(1, max_depth + 1):
+        if d == 1:
+            cands = loc_kernel_candidates(n_features, kern_list, cat_vars=cat_vars, depth=d)
+            parents = {name: "None" for name in cands}
+        else:
+            cands, parents = {}, {}
+            seen = list(search.keys())
+            for k in list(search.keys()):
+                if search[k]["depth"] != d - 1 or search[k]["try_next"] is False or k == "constant":
+                    continue
+                cur = search[k]["kernel"]
+                for op in ("sum", "split_product" if cur.name == "sum" else "product"):
+                    new = loc_kernel_candidates(n_features, kern_list, base_kern=cur, base_name=k,
+                                                cat_vars=cat_vars, depth=d, operation=op, prev_models=seen)
+                    for name, kern in new.items():
+                        cands[name], parents[name] = kern, k
+                        edges.append((k, name))
+                    seen += list(new.keys())
+        fits = (yield cands) if cands else {}
+        for name, kern in cands.items():
+            if fits.get(name) is not None:
+                search[name] = _entry(kern, fits[name], d, parents[name])
+        if not any(v["depth"] == d for v in search.values()):
+            break
+        best_name = _best_at(search, d)
+        if best_name == "constant":
+            break
+        stop = early_stopping and d > 1 and not check_if_better_metric(search, d)
+        if not stop and d != max_depth and not keep_all:
+            keep_top_k(search, depth=d, metric_diff=metric_diff)
+        if prune:
+            best_bic, best_name, pc = do_prune(d)
+            pfits = (yield pc) if pc else {}
+            for name, kern in pc.items():
+                f = pfits.get(name)
+                if f is not None and f["bic"] < best_bic:
+                    search[name] = _entry(kern, f, d, best_name)
+        if stop:
+            break
+    best_model_name = min((v["bic"], v["depth"], k) for k, v in search.items())[2]
+    models = {best_model_name: search[best_model_name]} if keep_only_best else search
+    return {"models": models, "edges": edges, "best_model": best_model_name, "depth_reached": d}
+
+
+# ---------------------------------------------------------------------------------------------
+# pooled scoring of candidates on the GPU
+# ---------------------------------------------------------------------------------------------
+def structure_signature(spec: ModelSpec) -> str:
+    return json.dumps(spec.to_dict(), sort_keys=True)
+
+
+class GpuScorer:
+    """Scores (column, kernel) candidates: one Problem per distinct structure, all its columns in one
+    batched fit.  This is `kernel_test` (model_search.py:2239-2334) for penalization_factor = 0,
+    `num_restart <= 1`: L-BFGS-B from the default values, `bic = round(2k - 2 log_posterior, 2)` with k =
+    number of trainable Parameter objects (q_mu and q_sqrt of the reference's SVGP included, hence + 2)."""
+
+    def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None):
+        from .engine import lbfgs_opts
+        from .model_classes import default_context
+
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.Y = np.ascontiguousarray(Y, dtype=np.float64)
+        self.ctx = context or default_context()
+        self.max_batch = max_batch
+        # structure batches in flight: each is its own Problem (own HIP streams) driven from its own host
+        # thread - the C-ABI calls release the GIL, hold no global state and set the device themselves.
+        # A search step is many small batches (a handful of columns per structure), each launch-latency
+        # bound on its own, so they are overlapped on the GPU instead of queued behind one another.
+        self.workers = int(workers if workers is not None else os.environ.get("WV_SEARCH_WORKERS", 16))
+        self.opts = lbfgs_opts(maxiter=num_opt_iter)
+        self.n_fits = 0
+        self.n_structures = 0
+        self.cache: Dict[tuple, dict] = {}
+
+    def _spec(self, kernel) -> ModelSpec:
+        return ModelSpec(kernel, self.X.shape[1], K.GaussianLikelihood(), K.ConstantMean())
+
+    def __call__(self, tasks: List[tuple]) -> List[Optional[dict]]:
+        """tasks: [(column, kernel)] -> [fit dict or None] in the same order."""
+        from .engine import Problem
+        from .model_search import _default_batch
+
+        specs = [self._spec(kern) for _, kern in tasks]
+        sigs = [structure_signature(sp) for sp in specs]
+        out: List[Optional[dict]] = [None] * len(tasks)
+        todo = [i for i in range(len(tasks)) if (tasks[i][0], sigs[i]) not in self.cache]
+        # group by structure; keep first-seen order so every rank builds the same task list
+        groups: Dict[str, List[int]] = {}
+        for i in todo:
+            groups.setdefault(sigs[i], []).append(i)
+        order = [i for g in groups.values() for i in g]
+        width = max([specs[i].n_trainable for i in order], default=0)
+        costs = np.array([specs[i].n_trainable for i in order], dtype=np.float64)
+        N = self.X.shape[0]
+
+        def fit_shard(ids):
+            rec = np.full((len(ids), 5 + width), np.nan)
+            mine = [order[j] for j in ids]
+            by_sig: Dict[str, List[int]] = {}
+            for row, i in enumerate(mine):
+                by_sig.setdefault(sigs[i], []).append(row)
+
+            def fit_structure(rows):
+                sp = specs[mine[rows[0]]]
+                cols = np.array([tasks[mine[r]][0] for r in rows], dtype=np.int32)
+                mb = self.max_batch or min(len(rows), _default_batch(N))
+                prob = Problem(self.ctx, self.X, self.Y, sp, max_batch=max(1, mb))
+                try:
+                    res = prob.fit(cols, np.tile(sp.unconstrain(), (len(rows), 1)), self.opts)
+                finally:
+                    prob.close()
+                rec[rows, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
+                rec[rows, 5:5 + sp.n_trainable] = res["u"]
+
+            # heaviest first; device memory in flight is bounded by workers x one Problem
+            work = sorted(by_sig.values(), key=lambda rows: -len(rows) * specs[mine[rows[0]]].n_trainable)
+            per_problem = max(1, min(max(len(r) for r in work), _default_batch(N))) * 2 * (N + 64) ** 2 * 8
+            nw = max(1, min(self.workers, len(work), (48 << 30) // per_problem))
+            if nw <= 1:
+                for rows in work:
+                    fit_structure(rows)
+            else:
+                with ThreadPoolExecutor(max_workers=nw) as pool:
+                    for f in [pool.submit(fit_structure, rows) for rows in work]:
+                        f.result()
+            return rec
+
+        if order:
+            rank, world = parallel.dist_info()
+            rec = parallel.sharded_map(len(order), fit_shard, costs=costs, width=5 + width) if world > 1 \
+                else fit_shard(np.arange(len(order)))
+            self.n_fits += len(order)
+            self.n_structures += len(groups)
+            for j, i in enumerate(order):
+                sp = specs[i]
+                loss = rec[j, 0]
+                if not np.isfinite(loss):
+                    self.cache[(tasks[i][0], sigs[i])] = None
+                    continue
+                k_count = sum(1 for q in sp.param_objs if q.trainable) + 2
+                self.cache[(tasks[i][0], sigs[i])] = {
+                    "bic": round(calc_bic(loglik=-loss, n=N, k=k_count), 2), "loss": float(loss),
+                    "lml": float(rec[j, 1]), "nit": int(rec[j, 2]), "nfev": int(rec[j, 3]),
+                    "status": int(rec[j, 4]), "u": rec[j, 5:5 + sp.n_trainable].copy()}
+        for i in range(len(tasks)):
+            out[i] = self.cache[(tasks[i][0], sigs[i])]
+        return out
+
+
+def run_searches(columns: Sequence[int], n_features: int, kern_list: Sequence, scorer: Callable,
+                 cat_vars: Sequence[int] = (), verbose: bool = False, **search_kwargs) -> Dict[int, dict]:
+    """Advance one `full_kernel_search_steps` generator per output column in lock step, pooling the
+    candidates of all columns into one `scorer` call per step."""
+    gens, requests, results = {}, {}, {}
+    for c in columns:
+        g = full_kernel_search_steps(n_features, kern_list, cat_vars=cat_vars, **search_kwargs)
+        try:
+            requests[c] = next(g)
+            gens[c] = g
+        except StopIteration as e:  # pragma: no cover - a search always scores depth 1
+            results[c] = e.value
+    step = 0
+    while requests:
+        tasks, owner = [], []
+        for c, cands in requests.items():
+            for name, kern in cands.items():
+                tasks.append((c, kern))
+                owner.append((c, name))
+        fits = scorer(tasks)
+        step += 1
+        if verbose:
+            print(f"search step {step}: {len(tasks)} candidate fits over {len(requests)} outputs")
+        per_col: Dict[int, dict] = {c: {} for c in requests}
+        for (c, name), f in zip(owner, fits):
+            per_col[c][name] = f
+        nxt = {}
+        for c in list(requests):
+            try:
+                nxt[c] = gens[c].send(per_col[c])
+            except StopIteration as e:
+                results[c] = e.value
+        requests = nxt
+    return results

@@ -19,7 +19,7 @@ from . import kernels as K
 from .engine import Context, Problem, lbfgs_opts
 from .spec import ModelSpec
 from .spec import _expand
-from .utilities import (calc_bic, calc_feature_importance_components, find_variance_components,
+from .utilities import (calc_bic, calc_feature_importance_components, calc_rsquare, find_variance_components,
                         print_kernel_names, search_through_kernel_list_)
 
 _default_ctx: Optional[Context] = None
@@ -149,9 +149,11 @@ class PSVGP:
         prob.close()
         return mean[:, None], var[:, None]
 
-    def component_means(self, data=None):
+    def component_means(self, data=None, only=False):
         """[full model, without additive component 0, 1, ...] training means of the whitened SVGP the
-        reference evaluates in calc_feature_importance_components (utilities.py:614-707)."""
+        reference evaluates in calc_feature_importance_components (utilities.py:614-707); with `only`,
+        [full, component 0 alone, 1 alone, ...] as individual_kernel_predictions does for calc_rsquare
+        (utilities.py:162-172, 770-780)."""
         spec, prob = self._problem()
         comps = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
         # additive component k owns a contiguous run of flattened terms (products of sums expand)
@@ -163,7 +165,7 @@ class PSVGP:
         if self.kernel.name == "sum":
             for k in range(len(comps)):
                 own = ((1 << counts[k]) - 1) << int(starts[k])
-                masks.append(full & ~own)
+                masks.append(own if only else full & ~own)
         out = prob.whitened_means(0, spec.theta(), masks)
         prob.close()
         return out

@@ -312,6 +312,68 @@ class GPSearch:
         return self.sweep_results
 
 
+    # ------------------------------------------------------------------------------------------
+    def run_search(self, kernels=None, max_depth=5, early_stopping=True, prune=True, keep_all=False,
+                   metric_diff=6, num_restart=1, random_seed=None, num_jobs=-1, verbose=False, debug=False,
+                   keep_only_best=True, max_batch=None, context=None, scorer=None):
+        """Stepwise compositional kernel search for every output column (model_search.py:1069-1250 ->
+        `full_kernel_search` :2987-3273).  Default `kernels` are the reference's: SquaredExponential,
+        Matern12, Lin, Periodic(SquaredExponential).
+
+        The candidates of all output columns at one search step are pooled and fitted in batched GPU
+        calls (waveome_amd/kernel_search.py); `num_jobs` is accepted and ignored, `num_restart > 1`
+        (random restarts inside `kernel_test`) is not implemented.  `scorer` replaces the GPU scorer
+        (test seam: tests/ drive the search logic with the CPU oracle).  Sets `self.models[out]` (the
+        best model, fitted), `self.search_info[out]` = {"models", "edges", "best_model", "var_exp"}."""
+        from . import kernel_search as ks
+        from .utilities import calc_rsquare
+
+        self.model_selection_type = "stepwise"
+        self.verbose = verbose
+        if self.likelihood != "gaussian":
+            raise NotImplementedError("only outcome_likelihood='gaussian' is implemented on the GPU path")
+        if num_restart > 1:
+            raise NotImplementedError("run_search with num_restart > 1 (random restarts per candidate)")
+        if kernels is None:
+            kernels = [K.SquaredExponential(), K.Matern12(), K.Lin(), K.Periodic(K.SquaredExponential())]
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        Xn = self.X.to_numpy(dtype=np.float64)
+        Yn = self.Y.to_numpy(dtype=np.float64)
+        P = Yn.shape[1]
+        print(f"Building {len(self.out_names)} models...")
+        start_time = time.time()
+        if scorer is None:
+            scorer = ks.GpuScorer(Xn, Yn, context=context, max_batch=max_batch)
+        out = ks.run_searches(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
+                              max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
+                              early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)
+        self.models, self.search_info = {}, {}
+        for p, feat in enumerate(self.out_names):
+            res = out[p]
+            best = res["models"][res["best_model"]]
+            mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=K.ConstantMean(), kernel=best["kernel"], verbose=verbose,
+                        penalized_options={"penalization_factor": 0.0}, context=context)
+            mspec = mod._spec()
+            u = np.asarray(best["fit"].get("u", []), dtype=np.float64)
+            if len(u) == mspec.n_trainable and len(u):
+                mspec.assign_theta(mspec.constrain(u))
+            mod.fit_result = {k_: v for k_, v in best["fit"].items() if k_ != "u"}
+            mod.optimizer = "scipy"
+            mod.kernel_name = res["best_model"]
+            best["model"] = mod
+            if scorer.__class__ is ks.GpuScorer:
+                res["var_exp"] = calc_rsquare(mod)
+            self.models[feat] = mod
+            self.search_info[feat] = res
+        self.search_stats = {"fits": getattr(scorer, "n_fits", None),
+                             "structures": getattr(scorer, "n_structures", None),
+                             "seconds": time.time() - start_time}
+        elapsed_time = np.round((time.time() - start_time) / 60, 1)
+        print(f"Finished {len(self.out_names)} models (100%),", f"elapsed time: {elapsed_time} minutes")
+        return None
+
+
 def _default_batch(n: int) -> int:
     """Fits in flight per GPU: two N x N float64 matrices per slot, capped at ~64 GiB of HBM."""
     npad = (n + 63) // 64 * 64

@@ -75,7 +75,9 @@ def broadcast_array(arr: Optional[np.ndarray], src: int = 0, device=None):
 def gather_records(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, device=None) -> np.ndarray:
     """All-gather fixed-width float64 records; returns [n_tasks, width] ordered by task id on every rank."""
     rank, world = dist_info()
-    local = np.ascontiguousarray(local, dtype=np.float64).reshape(len(local_ids), -1)
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if len(local_ids):  # (an empty shard arrives as [0, width]: nothing to infer)
+        local = local.reshape(len(local_ids), -1)
     width = local.shape[1]
     if world == 1:
         out = np.empty((n_tasks, width))
@@ -100,13 +102,17 @@ def gather_records(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, devic
     return out
 
 
-def sharded_map(n_tasks: int, fn: Callable[[np.ndarray], np.ndarray], costs=None, device=None) -> np.ndarray:
-    """Run fn(task_indices) -> [len, width] records on this rank's shard and gather all records."""
+def sharded_map(n_tasks: int, fn: Callable[[np.ndarray], np.ndarray], costs=None, device=None,
+                width: Optional[int] = None) -> np.ndarray:
+    """Run fn(task_indices) -> [len, width] records on this rank's shard and gather all records.
+    With fewer tasks than ranks some shards are empty: pass the record `width` so that those ranks
+    can still take part in the gather."""
     rank, world = dist_info()
     ids = shard_tasks(n_tasks, rank, world, costs)
-    rec = fn(ids) if len(ids) else np.zeros((0, 1))
     if len(ids) == 0:
-        # width unknown locally: learn it from the gather by sending an empty shard of width 1 is
-        # not possible, so require at least as many tasks as ranks
-        raise ValueError("sharded_map needs n_tasks >= world_size")
+        if width is None:
+            raise ValueError("sharded_map needs n_tasks >= world_size (or an explicit record width)")
+        rec = np.zeros((0, int(width)))
+    else:
+        rec = fn(ids)
     return gather_records(rec, ids, n_tasks, device=device)

@@ -1,6 +1,6 @@
 """Hot-path subset of waveome/utilities.py, GPflow-free.
 
-calc_bic (:77-95), print_kernel_names (:366-383), find_variance_components (:1012-1062),
+calc_bic (:77-95), calc_rsquare (:131-188), check_if_model_exists (:281-307), print_kernel_names (:366-383), find_variance_components (:1012-1062),
 keep_kernel_lengthscale_ / search_through_kernel_list_ (:1136-1184),
 freeze_variance_parameters (:977-986).  Same names, argument meaning and return shapes."""
 from __future__ import annotations
@@ -13,6 +13,37 @@ from . import kernels as K
 def calc_bic(loglik: float, n: int, k: int):
     """2k - 2 loglik (the reference's 'BIC' does not use log n, waveome/utilities.py:94-95)."""
     return 2 * k - 2 * loglik
+
+
+def check_if_model_exists(model_name, model_list):
+    """True when a model with the same additive components (product factors in any order) is in
+    `model_list` (waveome/utilities.py:281-307; components compare as sorted character strings there too)."""
+    target = set("".join(sorted(x)) for x in model_name.split("+"))
+    for other in model_list:
+        if target == set("".join(sorted(x)) for x in other.split("+")):
+            return True
+    return False
+
+
+def calc_rsquare(m, data=None):
+    """R-squared share of each additive component, then the residual share (waveome/utilities.py:131-188).
+    `m.component_means(data, only=True)` supplies [full, component 0 alone, 1 alone, ...] training means."""
+    X, Y = m.data if data is None else data
+    Y = np.asarray(Y, dtype=np.float64).reshape(-1, 1)
+    sse = np.sum((Y - Y.mean()) ** 2)
+    mu_all_hat, _ = m.predict_y(X)
+    total_rsq = 1 - (np.sum((Y - mu_all_hat) ** 2) / sse)
+    rsq = []
+    k = m.kernel
+    if k.name == "sum":
+        means = m.component_means(data, only=True)
+        ssr_list = [np.sum((mu_all_hat - means[1 + i].reshape(-1, 1)) ** 2) for i in range(len(k.kernels))]
+        for i in range(len(k.kernels)):
+            rsq += [np.round(total_rsq * (1 - ssr_list[i] / sum(ssr_list)), 3)]
+    else:
+        rsq += [np.round(total_rsq, 3)]
+    rsq += [np.round(1 - total_rsq, 3)]
+    return rsq
 
 
 def print_kernel_names(kernel, with_idx=False):
