@@ -228,3 +228,79 @@ def test_gpu_search_matches_oracle_scored_search():
         assert abs(m.training_loss() - got["models"][got["best_model"]]["fit"]["loss"]) < 1e-6
         assert len(got["var_exp"]) == (len(m.kernel.kernels) if m.kernel.name == "sum" else 1) + 1
     assert gps.search_stats["fits"] > 30
+
+
+# ---------------------------------------------------------------------------------------------
+# f-3: folds, random restarts and the k-fold search over penalisation factors
+# ---------------------------------------------------------------------------------------------
+def test_make_folds_partitions_rows_and_keeps_units_together():
+    from waveome_amd.regularization import make_folds
+
+    X = np.column_stack([np.arange(11.0), np.repeat(np.arange(6.0), 2)[:11]])
+    folds = make_folds(X, None, k_fold=3, random_seed=7)
+    assert sorted(np.concatenate(folds).tolist()) == list(range(11))
+    assert [len(f) for f in folds] == [4, 4, 3]  # divmod split (regularization.py:266-270)
+    # the documented recipe: seed, shuffle arange, split
+    np.random.seed(7)
+    idx = np.arange(11)
+    np.random.shuffle(idx)
+    assert folds[0].tolist() == idx[:4].tolist() and folds[2].tolist() == idx[8:].tolist()
+    ufolds = make_folds(X, 1, k_fold=3, random_seed=7)
+    assert sorted(np.concatenate(ufolds).tolist()) == list(range(11))
+    for f in ufolds:  # a unit's rows never straddle folds
+        units = set(X[f, 1])
+        assert all(set(X[g, 1]).isdisjoint(units) for g in ufolds if g is not f)
+    with pytest.raises(AssertionError):
+        make_folds(X[:4], 1, k_fold=3)
+
+
+def _search_model(n=60, seed=11):
+    from waveome_amd.model_classes import PSVGP
+
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([rng.normal(size=n), rng.normal(size=n)])
+    y = np.sin(1.5 * X[:, 0]) + 0.2 * rng.normal(size=n)
+    kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.SquaredExponential(active_dims=[1])])
+    return PSVGP(X, y[:, None], kernel=kern, penalized_options={"penalization_factor": 1.0}), X, y
+
+
+@pytest.mark.gpu
+def test_random_restart_optimize_keeps_the_best_lml():
+    m, X, y = _search_model()
+    m.random_restart_optimize(num_restart=3, randomize_kwargs={"random_seed": 5})
+    starts = m._restart_points(3, random_seed=5)
+    spec = m._spec().to_dict()
+    best = max((O.fit(spec, X, y, u0=u) for u in starts), key=lambda r: r["lml"])
+    assert abs(m.fit_result["lml"] - best["lml"]) <= 1e-6 * abs(best["lml"])
+    assert abs(m.maximum_log_likelihood_objective() - best["lml"]) <= 1e-6 * abs(best["lml"])
+
+
+@pytest.mark.gpu
+def test_penalization_search_matches_oracle_table():
+    from waveome_amd.regularization import make_folds
+
+    m, X, y = _search_model()
+    factors = [0.0, 1.0, 30.0]
+    m.penalization_search(penalization_factor_list=factors, k_fold=3, num_restart=2, random_seed=3,
+                          fit_best=True, selection_type="se")
+    tab = m.penalization_search_results
+    assert tab.shape == (9, 3)
+    folds = make_folds(X, None, 3, 3)
+    starts = m._restart_points(2, random_seed=3)
+    want = []
+    for h, fold in enumerate(folds):
+        Xtr, ytr = np.delete(X, fold, axis=0), np.delete(y, fold)
+        for pf in factors:
+            spec = m._twin(Xtr, ytr[:, None], pf)._spec().to_dict()
+            r = max((O.fit(spec, Xtr, ytr, u0=u) for u in starts), key=lambda r_: r_["lml"])
+            mu, var = O.predict(spec, r["theta"], Xtr, ytr, X[fold], include_noise=True)
+            ld = -0.5 * (np.log(2 * np.pi) + np.log(var) + (y[fold] - mu) ** 2 / var)
+            want.append([pf, h, ld.mean()])
+    want = np.array(want)
+    got = tab[np.lexsort((tab[:, 0], tab[:, 1]))]
+    np.testing.assert_array_equal(got[:, :2], want[:, :2])
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=2e-4, atol=2e-4)
+    # selection rule: best mean minus one standard error
+    score = {f: want[want[:, 0] == f, 2].mean() - want[want[:, 0] == f, 2].std() / np.sqrt(3) for f in factors}
+    assert m.penalization_factor == max(score, key=score.get)
+    assert m.fit_result is not None and np.isfinite(m.fit_result["lml"])

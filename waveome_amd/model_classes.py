@@ -19,7 +19,7 @@ from . import kernels as K
 from .engine import Context, Problem, lbfgs_opts
 from .spec import ModelSpec
 from .spec import _expand
-from .utilities import (calc_bic, calc_feature_importance_components, calc_rsquare, find_variance_components,
+from .utilities import (_gaussian_logdensity, calc_bic, calc_feature_importance_components, calc_rsquare, find_variance_components,
                         print_kernel_names, search_through_kernel_list_)
 
 _default_ctx: Optional[Context] = None
@@ -55,6 +55,8 @@ class PSVGP:
         self.num_inducing_points = X.shape[0]  # exact GP: every training point (Z = X)
         self._ctx = context
         self.fit_result = None
+        self.unit_col = None  # model_classes.py:814
+        self.penalization_search_results = None
         self.set_penalization_factor(penalized_options.get("penalization_factor", 1.0))
         self.update_kernel_name()
 
@@ -148,6 +150,137 @@ class PSVGP:
         mean, var = prob.predict(0, spec.theta(), include_noise=True, Xnew=self._xnew(Xnew))
         prob.close()
         return mean[:, None], var[:, None]
+
+    def predict_log_density(self, data):
+        """log N(y | mean_f, var_f + sigma^2) per row (gpflow GPModel.predict_log_density, Gaussian likelihood)."""
+        X, Y = data
+        mean, var = self.predict_y(X)
+        Y = np.asarray(Y, dtype=np.float64).reshape(-1, 1)
+        return _gaussian_logdensity(Y, mean, var)[:, 0]
+
+    # ---- restarts and the k-fold search over penalisation factors ----------------------------------
+    def _fit_tasks(self, X, Y, factors, starts, num_opt_iter=50000):
+        """Fit one task per row of `starts` (unconstrained start points) on data (X, Y[:, 0]) with
+        penalisation factor factors[i]; tasks with a prior share one batched call with a per-task
+        Horseshoe scale, factor-0 tasks (no prior, :844-861) share another."""
+        ctx = self._ctx or default_context()
+        factors = np.asarray(factors, dtype=np.float64)
+        out = {k: np.zeros(len(factors)) for k in ("loss", "lml", "nit", "nfev", "status")}
+        out["u"] = np.zeros_like(starts)
+        for with_prior in (True, False):
+            sel = np.nonzero((factors > 0) == with_prior)[0]
+            if len(sel) == 0:
+                continue
+            twin = self._twin(X, Y, 1.0 if with_prior else 0.0)
+            prob = Problem(ctx, X, Y, twin._spec(), max_batch=max(1, min(len(sel), 64)))
+            try:
+                res = prob.fit(np.zeros(len(sel), dtype=np.int32), starts[sel], lbfgs_opts(maxiter=num_opt_iter),
+                               prior_scale=(1.0 / factors[sel]) if with_prior else None)
+            finally:
+                prob.close()
+            for k in ("loss", "lml", "nit", "nfev", "status"):
+                out[k][sel] = res[k]
+            out["u"][sel] = res["u"]
+        return out
+
+    def _twin(self, X, Y, penalization_factor):
+        """Same structure, flags and values on other data / another factor (the reference's deepcopy(self))."""
+        twin = PSVGP(X, Y, mean_function=self.mean_function, kernel=self.kernel, verbose=self.verbose,
+                     penalized_options={"penalization_factor": penalization_factor}, context=self._ctx)
+        twin.likelihood = copy.deepcopy(self.likelihood)
+        twin.unit_col = self.unit_col
+        return twin
+
+    def _restart_points(self, num_restart, loc=0.0, scale=1.0, random_seed=None):
+        """Start points of `random_restart_optimize` (:472-524): restart i draws every unconstrained
+        value ~ N(loc, scale) under `np.random.seed(seed)` with seed = i for random_seed None, else
+        random_seed + i + 1 (:498-503, 181-234).  (The reference's draws also feed q_mu / q_sqrt, which this
+        exact-GP path does not have, so the numbers differ from the reference's for the same seed.)"""
+        nt = self._spec().n_trainable
+        pts = np.empty((num_restart, nt))
+        for i in range(num_restart):
+            np.random.seed(i if random_seed is None else random_seed + i + 1)
+            pts[i] = np.random.normal(loc=loc, scale=scale, size=nt)
+        return pts
+
+    def random_restart_optimize(self, data=None, num_restart=5, randomize_kwargs={}, optimize_kwargs={}):
+        """`num_restart` randomised fits in one batched call; keeps the one with the highest
+        `maximum_log_likelihood_objective` (no prior term, :511-519)."""
+        X, Y = self.data if data is None else (np.asarray(data[0], dtype=np.float64),
+                                               np.asarray(data[1], dtype=np.float64).reshape(len(data[0]), -1))
+        starts = self._restart_points(num_restart, **randomize_kwargs)
+        res = self._fit_tasks(X, Y, np.full(num_restart, self.penalization_factor), starts,
+                              optimize_kwargs.get("num_opt_iter", 50000))
+        lml = np.where(np.isfinite(res["lml"]), res["lml"], -np.inf)
+        best = int(np.argmax(lml))
+        spec = self._spec()
+        spec.assign_theta(spec.constrain(res["u"][best]))
+        self.fit_result = {k: v[best] for k, v in res.items()}
+        self.optimizer = "scipy"
+        return None
+
+    def penalization_search(self, data=None, penalization_factor_list=[0.0, 1.0, 10.0, 100.0], k_fold=3,
+                            fit_best=True, max_jobs=-1, show_progress=True, parallel_object=None,
+                            randomization_options={}, optimization_options={}, random_seed=None, num_restart=5,
+                            selection_type="se"):
+        """k-fold search over penalisation factors (model_classes.py:866-998): every (factor, fold) pair
+        is `num_restart` randomised fits on the training rows, scored by the mean holdout
+        `predict_log_density`; the factor with the best mean (minus one standard error for
+        selection_type="se") wins and, with fit_best, is refitted on all the data.
+
+        All factors x restarts of one fold are one batched GPU call (same training matrix).  The
+        reference's `parallel_fit` deep-copies the model but never applies `pf` to the copy (:900-918), so
+        there every factor is fitted under the model's current prior; here the factor is applied, which is
+        what the surrounding selection logic assumes.  `max_jobs`, `show_progress`, `parallel_object` are
+        accepted and ignored."""
+        from .regularization import make_folds
+
+        data = self.data if data is None else data
+        X = np.asarray(data[0], dtype=np.float64)
+        Y = np.asarray(data[1], dtype=np.float64).reshape(len(X), -1)
+        folds = make_folds(X, self.unit_col, k_fold, random_seed)
+        rand = dict(randomization_options)
+        rand.setdefault("random_seed", random_seed)
+        factors = [float(f) for f in penalization_factor_list]
+        starts = self._restart_points(num_restart, **rand)
+        n_opt = optimization_options.get("num_opt_iter", 50000)
+        results = []
+        spec = self._spec()
+        for h, fold in enumerate(folds):
+            Xtr, Ytr = np.delete(X, fold, axis=0), np.delete(Y, fold, axis=0)
+            task_f = np.repeat(factors, num_restart)
+            res = self._fit_tasks(Xtr, Ytr, task_f, np.tile(starts, (len(factors), 1)), n_opt)
+            for i, pf in enumerate(factors):
+                blk = slice(i * num_restart, (i + 1) * num_restart)
+                lml = np.where(np.isfinite(res["lml"][blk]), res["lml"][blk], -np.inf)
+                u = res["u"][blk][int(np.argmax(lml))]
+                twin = self._twin(Xtr, Ytr, pf)
+                tspec = twin._spec()
+                tspec.assign_theta(tspec.constrain(u))
+                holdout = np.mean(twin.predict_log_density((X[fold], Y[fold])))
+                results.append([pf, h, holdout])
+        parallel_results = np.array(results)
+        self.penalization_search_results = parallel_results
+        max_val, max_factor = -np.inf, -np.inf
+        for factor in factors:
+            vals = parallel_results[parallel_results[:, 0] == factor, 2]
+            cur_val = vals.mean()
+            if selection_type == "se":
+                cur_val -= vals.std() / np.sqrt(k_fold)
+            if cur_val > max_val:
+                max_factor, max_val = factor, cur_val
+        best_factor = max_factor
+        if max_factor == -np.inf:
+            if self.verbose:
+                print("Search error, returning no penalization")
+            best_factor = 0.0
+        if self.verbose:
+            print(f"Best penalization factor found from search: {best_factor}")
+        if fit_best:
+            self.set_penalization_factor(best_factor)
+            self.random_restart_optimize(data=(X, Y), randomize_kwargs=rand, optimize_kwargs=optimization_options,
+                                         num_restart=num_restart)
+        return None
 
     def component_means(self, data=None, only=False):
         """[full model, without additive component 0, 1, ...] training means of the whitened SVGP the

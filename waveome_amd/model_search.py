@@ -206,7 +206,8 @@ class GPSearch:
         self.models = {}
         for p, feat in enumerate(self.out_names):
             block = rec[p * n_starts:(p + 1) * n_starts]
-            best = block[np.argmin(block[:, 0])]  # lowest training loss over restarts
+            # restarts: keep the highest maximum_log_likelihood_objective (model_classes.py:511-519)
+            best = block[np.argmax(np.where(np.isfinite(block[:, 1]), block[:, 1], -np.inf))]
             mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
                         penalized_options={"penalization_factor": float(best[5])},
                         variational_options=variational_options, context=context)
@@ -296,7 +297,7 @@ class GPSearch:
             k_count = sum(1 for q in sp.param_objs if q.trainable) + 2  # + q_mu, q_sqrt (utilities.py:94-95)
             for p, feat in enumerate(self.out_names):
                 blk = rec[(s_ * P + p) * n_starts:(s_ * P + p + 1) * n_starts]
-                best = blk[np.argmin(blk[:, 0])]
+                best = blk[np.argmax(np.where(np.isfinite(blk[:, 1]), blk[:, 1], -np.inf))]
                 loglik = -best[0]  # log posterior density = LML + log prior = -training loss
                 rows.append({"output": feat, "structure": nm, "loss": best[0], "lml": best[1],
                              "bic": round(2 * k_count - 2 * loglik, 2), "nit": int(best[2]), "nfev": int(best[3]),

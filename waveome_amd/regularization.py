@@ -3,12 +3,36 @@
 Same argument names, defaults and term order (unit categorical, categoricals, numeric x base
 kernels, optional unit x numeric, categorical x numeric (default on, categorical variance frozen),
 optional numeric x numeric), with the `ranks` machinery reduced to rank 1 (it only matters to the
-multi-output LMC model, which is outside this path)."""
+multi-output LMC model, which is outside this path).  Also `make_folds` (:245-276), the fold
+builder of `PSVGP.penalization_search`."""
 from __future__ import annotations
 
 import copy
 
+import numpy as np
+
 from . import kernels as K
+
+
+def make_folds(X, unit_col, k_fold=5, random_seed=None):
+    """Row indices of k folds, sampled per observation or per unit (waveome/regularization.py:245-276):
+    same shuffle (`np.random.seed` + `np.random.shuffle`) and the same divmod split, so a seed gives the
+    reference's folds."""
+    if random_seed is not None:
+        np.random.seed(random_seed)
+    if unit_col is None:
+        sample_idx = np.arange(0, X.shape[0])
+    else:
+        sample_idx = np.unique(X[:, unit_col])
+        assert len(sample_idx) >= k_fold, (
+            "Not enough unique units for number of folds requested, "
+            f"{len(sample_idx)} unit(s) < {k_fold} fold(s)")
+    np.random.shuffle(sample_idx)
+    div, mod = divmod(len(sample_idx), k_fold)
+    folds = [sample_idx[(i * div + min(i, mod)):((i + 1) * div + min(i + 1, mod))] for i in range(k_fold)]
+    if unit_col is not None:
+        folds = [np.where(np.isin(X[:, unit_col], f))[0] for f in folds]
+    return folds
 
 
 def full_kernel_build(cat_vars=[], num_vars=[], unit_idx=None, var_names=None, second_order_numeric=False,
