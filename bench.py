@@ -70,6 +70,21 @@ def cpu_baseline(X, Y, seconds_budget=20.0):
                       f"evaluations, {dt:.1f} s) of oracle/gp_oracle.py, scaled to 100 iterations"}
 
 
+def pmc_traffic(fits_per_launch):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process, so
+    the figure comes from the committed rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, corrected as
+    MI355X_MICROARCH.md prescribes; profiles/r01_traffic.json) of the same kernel on the same workload, scaled
+    to the fits one launch covers here.  None when the summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]["lauum_gemm"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    per_fit = (k["read_bytes"] + k["write_bytes"]) / k["fits_per_launch"]
+    return per_fit * fits_per_launch, "profiles/r01_traffic.json (offline rocprofv3 PMC passes, per fit x fits per launch)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +191,7 @@ def main():
         fits = float(table[:, 2].sum()) / 100.0 * args.steps
         nit_ok = bool(np.all(table[:, 2] == 100))
         ach = dom_stage["flops"] / (dom_stage["ms"] * 1e-3) / 1e12 if dom_stage["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(args.batch)
         out = {
             "metric": "GP model fits/sec (N=2048, fp64, 100 L-BFGS steps)",
             "value": fits / elapsed, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
@@ -193,7 +209,8 @@ def main():
                                          zip(*np.unique(table[:, 4], return_counts=True))}},
             "roofline": {"bound": "mfma", "kernel": f"gemm_f64_kernel<false, false, 128, 2, 0, 1> ({DOMINANT_STAGE})",
                          "achieved": ach, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches": dom_stage["launches"],
                          "avg_launch_ms": dom_stage["ms"] / max(1, dom_stage["launches"]),
                          "algorithmic_flops_per_launch": dom_stage["flops"] / max(1, dom_stage["launches"])},
