@@ -1,0 +1,191 @@
+"""float32 storage path (context dtype "float32": the reference's `set_precision("float32")`,
+waveome/utilities.py:34-49; BASELINE config C5) against float64 references.
+
+The N x N work matrices and their MFMA products are float32, everything else float64, so the
+tolerances are float32 ones and are written next to each assertion."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+from waveome_amd import ModelSpec
+from waveome_amd import kernels as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx32():
+    from waveome_amd.engine import Context
+
+    c = Context(0, dtype="float32")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx64():
+    from waveome_amd.engine import Context
+
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _data(seed, N, D=3, P=2):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, D))
+    Y = np.stack([np.sin((1 + p) * X[:, 0]) + 0.4 * X[:, 1] + 0.2 * rng.normal(size=N) for p in range(P)], axis=1)
+    return X, Y
+
+
+def _kernel():
+    return K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),
+                  K.Periodic(K.SquaredExponential(active_dims=[2]))])
+
+
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("nb", [3, 9])  # 9: the batch -> XCD mapping of launches with >= 8 matrices
+def test_f32_mfma_gemm(ctx32, a_kc, nb):
+    rng = np.random.default_rng(1)
+    M, N, Kd = 256, 192, 128
+    A = rng.normal(size=(nb, M, Kd) if a_kc else (nb, Kd, M)).astype(np.float32)
+    B = rng.normal(size=(nb, Kd, N)).astype(np.float32)
+    C0 = rng.normal(size=(nb, M, N)).astype(np.float32)
+    Am = A if a_kc else np.swapaxes(A, 1, 2)
+    want = -0.5 * np.einsum("bmk,bkn->bmn", Am.astype(np.float64), B.astype(np.float64)) + 2.0 * C0
+    got = ctx32.dbg_gemm(A, B, C0, a_kcontig=a_kc, b_kcontig=False, alpha=-0.5, beta=2.0)
+    # float32 accumulation over K = 128 terms of size ~1: a few 1e-6 relative to sqrt(K)
+    assert np.max(np.abs(got - want)) < 2e-4
+    got0 = ctx32.dbg_gemm(A, B, np.zeros_like(C0), a_kcontig=a_kc, b_kcontig=False)
+    assert np.max(np.abs(got0 - np.einsum("bmk,bkn->bmn", Am.astype(np.float64), B.astype(np.float64)))) < 2e-4
+
+
+def test_f32_factor_inverse_stages(ctx32, ctx64):
+    from waveome_amd.engine import Problem
+
+    N = 300  # Npad = 320: uneven splits of the recursion
+    X, Y = _data(5, N)
+    spec = ModelSpec(_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
+    theta = spec.theta()
+    p64 = Problem(ctx64, X, Y, spec, max_batch=1)
+    Ky = p64.gram(theta)
+    p64.close()
+    p32 = Problem(ctx32, X, Y, spec, max_batch=1)
+    K32 = p32.gram(theta)
+    assert np.max(np.abs(K32 - Ky)) < 5e-7 * np.max(np.abs(Ky))  # one float32 rounding of each element
+    L = np.linalg.cholesky(Ky)
+    Minv = np.linalg.inv(L)
+    Mgot = p32.dbg_stage(0, theta, 1)[:N, :N]
+    assert np.max(np.abs(np.tril(Mgot) - Minv)) < 2e-4 * np.max(np.abs(Minv))
+    Kinv = np.linalg.inv(Ky)
+    Kgot = np.tril(p32.dbg_stage(0, theta, 2)[:N, :N])
+    assert np.max(np.abs(Kgot - np.tril(Kinv))) < 2e-4 * np.max(np.abs(Kinv))
+    p32.close()
+
+
+@pytest.mark.parametrize("N", [64, 200, 1000])
+def test_f32_value_and_gradient_close_to_float64(ctx32, ctx64, N):
+    from waveome_amd.engine import Problem
+
+    X, Y = _data(7, N)
+    spec = ModelSpec(_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
+    rng = np.random.default_rng(2)
+    U = spec.unconstrain()[None, :] + 0.3 * rng.normal(size=(4, spec.n_trainable))
+    cols = np.array([0, 1, 0, 1], dtype=np.int32)
+    p64 = Problem(ctx64, X, Y, spec, max_batch=4)
+    f64, g64, _ = p64.value_grad(cols, U)
+    l64, _ = p64.lml(cols, np.stack([spec.constrain(u) for u in U]))
+    p64.close()
+    p32 = Problem(ctx32, X, Y, spec, max_batch=4)
+    f32, g32, st = p32.value_grad(cols, U)
+    l32, _ = p32.lml(cols, np.stack([spec.constrain(u) for u in U]))
+    p32.close()
+    assert np.all(st == 0)
+    np.testing.assert_allclose(l32, l64, rtol=2e-5)  # LML: float32 factorisation, float64 reductions
+    np.testing.assert_allclose(f32, f64, rtol=2e-5)
+    assert np.max(np.abs(g32 - g64)) < 2e-3 * np.max(np.abs(g64))
+
+
+def test_f32_fit_reaches_the_float64_optimum(ctx32, ctx64):
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(9, 400)
+    kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])])
+    spec = ModelSpec(kern, 3, K.GaussianLikelihood(), K.ConstantMean())
+    U0 = np.tile(spec.unconstrain(), (2, 1))
+    cols = np.array([0, 1], dtype=np.int32)
+    p64 = Problem(ctx64, X, Y, spec, max_batch=2)
+    r64 = p64.fit(cols, U0, lbfgs_opts())
+    p64.close()
+    p32 = Problem(ctx32, X, Y, spec, max_batch=2)
+    r32 = p32.fit(cols, U0, lbfgs_opts())
+    p32.close()
+    # float32 noise in the objective stops L-BFGS-B a little earlier; the optimum is the same
+    np.testing.assert_allclose(r32["loss"], r64["loss"], rtol=1e-4)
+    th32 = np.stack([spec.constrain(u) for u in r32["u"]])
+    th64 = np.stack([spec.constrain(u) for u in r64["u"]])
+    np.testing.assert_allclose(th32, th64, rtol=5e-2, atol=1e-2)  # flat directions (mean, tiny variances)
+
+
+def test_f32_unsupported_entries_say_so(ctx32):
+    from waveome_amd.engine import Problem
+
+    X, Y = _data(3, 100)
+    spec = ModelSpec(K.SquaredExponential(active_dims=[0]), 3, K.GaussianLikelihood(), K.ConstantMean())
+    p = Problem(ctx32, X, Y, spec, max_batch=1)
+    with pytest.raises(Exception, match="float32"):
+        p.predict(0, spec.theta())
+    p.close()
+
+
+def test_set_precision_switches_the_default_context():
+    from waveome_amd import utilities as U
+    from waveome_amd.model_classes import default_context
+
+    with pytest.raises(ValueError):
+        U.set_precision("float16")
+    U.set_precision("float32")
+    try:
+        assert U.get_precision() == "float32" and default_context().dtype == "float32"
+    finally:
+        U.set_precision("float64")
+    assert default_context().dtype == "float64"
+
+
+def test_config_c5_float32_n16384(ctx32, ctx64):
+    """BASELINE config C5: N = 16384, D = 4, sum_d Matern32[d], float32; value-only and value+gradient
+    against the float64 path on the same inputs."""
+    import time
+
+    from waveome_amd.engine import Problem
+
+    N, D = 16384, 4
+    rng = np.random.default_rng(9102 + 5)
+    X = rng.uniform(-3, 3, size=(N, D))
+    X = (X - X.mean(0)) / X.std(0, ddof=1)
+    Y = (np.sin(1.3 * X[:, 0]) + 0.5 * np.sin(2.1 * X[:, 1]) + 0.1 * rng.normal(size=N))[:, None]
+    spec = ModelSpec(K.Sum([K.Matern32(active_dims=[d]) for d in range(D)]), D, K.GaussianLikelihood(),
+                     K.ConstantMean())
+    th = spec.theta()
+    th[spec.noise] = 0.3
+    u = spec.unconstrain(th)[None, :]
+    cols = np.zeros(1, dtype=np.int32)
+    p64 = Problem(ctx64, X, Y, spec, max_batch=1)
+    f64, g64, _ = p64.value_grad(cols, u)
+    p64.close()
+    p32 = Problem(ctx32, X, Y, spec, max_batch=1)
+    p32.value_grad(cols, u)  # warm-up
+    t0 = time.perf_counter()
+    l32, st = p32.lml(cols, th[None, :])
+    t1 = time.perf_counter()
+    f32, g32, st2 = p32.value_grad(cols, u)
+    t2 = time.perf_counter()
+    p32.close()
+    assert st[0] == 0 and st2[0] == 0
+    print(f"C5 float32: value-only {t1 - t0:.3f} s ({N ** 3 / 3 / (t1 - t0) / 1e12:.1f} TFLOP/s), "
+          f"value+grad {t2 - t1:.3f} s ({N ** 3 / (t2 - t1) / 1e12:.1f} TFLOP/s); "
+          f"rel err value {abs(f32[0] - f64[0]) / abs(f64[0]):.2e}, "
+          f"grad {np.max(np.abs(g32 - g64)) / np.max(np.abs(g64)):.2e}")
+    assert abs(f32[0] - f64[0]) <= 1e-4 * abs(f64[0])
+    assert abs(-l32[0] - f64[0]) <= 1e-4 * abs(f64[0])
+    assert np.max(np.abs(g32 - g64)) <= 2e-2 * np.max(np.abs(g64))

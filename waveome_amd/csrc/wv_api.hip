@@ -220,8 +220,8 @@ int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out) {
     set_error("wv_ctx_create: out is NULL");
     return WV_E_BADARG;
   }
-  if (dtype != 0) {
-    set_error("wv_ctx_create: only dtype 0 (float64) is implemented in ABI v1");
+  if (dtype != 0 && dtype != 1) {
+    set_error("wv_ctx_create: dtype must be 0 (float64) or 1 (float32 matrices)");
     return WV_E_UNSUPPORTED;
   }
   int n = 0;
@@ -237,6 +237,7 @@ int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out) {
   WV_HIP_TRY(hipSetDevice(device_ordinal));
   auto* c = new wv_ctx();
   c->c.device = device_ordinal;
+  c->c.dtype = dtype;
   if (hipGetDeviceProperties(&c->c.prop, device_ordinal) != hipSuccess) {
     delete c;
     set_error("hipGetDeviceProperties failed");
@@ -275,7 +276,8 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_status) hipHostFree(g.h_status);
   }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
-                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part};
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.Kbuf32, p.Mbuf32, p.MTbuf32,
+                  p.Pbuf32};
   for (void* q : ptrs)
     if (q) hipFree(q);
   delete h;
@@ -297,6 +299,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   std::unique_ptr<wv_problem, void (*)(wv_problem*)> h(new wv_problem(), wv_problem_destroy);
   Problem& p = h->p;
   p.ctx = &ctx->c;
+  p.f32 = ctx->c.dtype == 1;
   std::string e = Spec::parse(spec, p.spec);
   if (!e.empty()) {
     set_error(e);
@@ -331,10 +334,14 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   };
   bool ok = alloc((void**)&p.dX, sizeof(double) * Np * D) && alloc((void**)&p.dY, sizeof(double) * Np * P) &&
             alloc((void**)&p.dspec, sizeof(DevSpec)) &&
-            alloc((void**)&p.Kbuf, sizeof(double) * mat * max_batch) &&
-            alloc((void**)&p.Mbuf, sizeof(double) * mat * max_batch) &&
-            alloc((void**)&p.MTbuf, sizeof(double) * mat * max_batch) &&
-            alloc((void**)&p.Pbuf, sizeof(double) * p.pbuf_elems() * max_batch) &&
+            (p.f32 ? alloc((void**)&p.Kbuf32, sizeof(float) * mat * max_batch) &&
+                         alloc((void**)&p.Mbuf32, sizeof(float) * mat * max_batch) &&
+                         alloc((void**)&p.MTbuf32, sizeof(float) * mat * max_batch) &&
+                         alloc((void**)&p.Pbuf32, sizeof(float) * p.pbuf_elems() * max_batch)
+                   : alloc((void**)&p.Kbuf, sizeof(double) * mat * max_batch) &&
+                         alloc((void**)&p.Mbuf, sizeof(double) * mat * max_batch) &&
+                         alloc((void**)&p.MTbuf, sizeof(double) * mat * max_batch) &&
+                         alloc((void**)&p.Pbuf, sizeof(double) * p.pbuf_elems() * max_batch)) &&
             alloc((void**)&p.dtheta, sizeof(double) * np * max_batch) &&
             alloc((void**)&p.dr, sizeof(double) * Np * max_batch) &&
             alloc((void**)&p.dz, sizeof(double) * Np * max_batch) &&
@@ -344,7 +351,7 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
             alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&
             alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
             alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
-  if (ok && Np <= 2048) ok = alloc((void**)&p.dsolve_part, sizeof(double) * (Np / 64) * Np * max_batch);
+  if (ok && Np <= 2048 && !p.f32) ok = alloc((void**)&p.dsolve_part, sizeof(double) * (Np / 64) * Np * max_batch);
   if (!ok) {
     set_error("device allocation failed (workspace for max_batch fits does not fit in HBM)");
     return WV_E_OOM;
@@ -353,9 +360,15 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   const int nwg = trace_nwg(p);
   WV_HIP_TRY(hipMemset(p.dX, 0, sizeof(double) * Np * D));
   WV_HIP_TRY(hipMemset(p.dY, 0, sizeof(double) * Np * P));
-  WV_HIP_TRY(hipMemset(p.Kbuf, 0, sizeof(double) * mat * max_batch));
-  WV_HIP_TRY(hipMemset(p.Mbuf, 0, sizeof(double) * mat * max_batch));
-  WV_HIP_TRY(hipMemset(p.MTbuf, 0, sizeof(double) * mat * max_batch));
+  if (p.f32) {
+    WV_HIP_TRY(hipMemset(p.Kbuf32, 0, sizeof(float) * mat * max_batch));
+    WV_HIP_TRY(hipMemset(p.Mbuf32, 0, sizeof(float) * mat * max_batch));
+    WV_HIP_TRY(hipMemset(p.MTbuf32, 0, sizeof(float) * mat * max_batch));
+  } else {
+    WV_HIP_TRY(hipMemset(p.Kbuf, 0, sizeof(double) * mat * max_batch));
+    WV_HIP_TRY(hipMemset(p.Mbuf, 0, sizeof(double) * mat * max_batch));
+    WV_HIP_TRY(hipMemset(p.MTbuf, 0, sizeof(double) * mat * max_batch));
+  }
   WV_HIP_TRY(hipMemset(p.dalpha, 0, sizeof(double) * Np * max_batch));
   WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * np * max_batch));
   WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -410,10 +423,18 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
                             hipMemcpyHostToDevice, g.stream));
   launch_gram(p, g.stream, g.slot0, 1, 0);
   WV_HIP_TRY(hipGetLastError());
-  WV_HIP_TRY(hipMemcpy2DAsync(K_out, sizeof(double) * p.N, p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad,
-                              sizeof(double) * p.Npad, sizeof(double) * p.N, p.N,
-                              hipMemcpyDeviceToHost, g.stream));
-  WV_HIP_TRY(hipStreamSynchronize(g.stream));
+  if (p.f32) {  // float32 storage: fetch as stored, widen on the host
+    std::vector<float> tmp((size_t)p.N * p.N);
+    WV_HIP_TRY(hipMemcpy2DAsync(tmp.data(), sizeof(float) * p.N, p.Kbuf32 + (int64_t)g.slot0 * p.Npad * p.Npad,
+                                sizeof(float) * p.Npad, sizeof(float) * p.N, p.N, hipMemcpyDeviceToHost, g.stream));
+    WV_HIP_TRY(hipStreamSynchronize(g.stream));
+    for (int64_t q = 0; q < p.N * p.N; ++q) K_out[q] = (double)tmp[q];
+  } else {
+    WV_HIP_TRY(hipMemcpy2DAsync(K_out, sizeof(double) * p.N, p.Kbuf + (int64_t)g.slot0 * p.Npad * p.Npad,
+                                sizeof(double) * p.Npad, sizeof(double) * p.N, p.N,
+                                hipMemcpyDeviceToHost, g.stream));
+    WV_HIP_TRY(hipStreamSynchronize(g.stream));
+  }
   // the device kernel fills lower tiles only; mirror on the host so the caller sees K_y = K_y'
   for (int64_t i = 0; i < p.N; ++i)
     for (int64_t j = i + 1; j < p.N; ++j) K_out[i * p.N + j] = K_out[j * p.N + i];
@@ -726,6 +747,10 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.f32) {
+    set_error("wv_predict: not implemented for float32 problems (create the problem on a float64 context)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = eval_one(p, col, theta);
   if (rc != WV_OK) return rc;
@@ -822,6 +847,10 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.f32) {
+    set_error("wv_whitened_means: not implemented for float32 problems (create the problem on a float64 context)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = eval_one(p, col, theta);  // alpha of the full model
   if (rc != WV_OK) return rc;

@@ -21,16 +21,29 @@ constexpr int DS = NB + 1;  // LDS row stride of the 64x64 diagonal block
 // A non-positive / NaN pivot sets status[slot] = 1 and is replaced by 1 so the pipeline
 // keeps running on finite numbers (the host reports +inf for that task).
 // ---------------------------------------------------------------------------------------
+// 4 consecutive elements in their own type
+__device__ inline void ld4(const double* __restrict__ p, double (&v)[4]) { load4(p, v); }
+__device__ inline void st4(double* __restrict__ p, const double (&v)[4]) { store4(p, v); }
+__device__ inline void ld4(const float* __restrict__ p, float (&v)[4]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ inline void st4(float* __restrict__ p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ inline double rsq(double x) { return rsqrt(x); }
+__device__ inline float rsq(float x) { return rsqrtf(x); }
+
 // Triangular-inverse combine step of size H inside the 64x64 block: for every 2H diagonal block
 // X21 = -X22 (L21 X11), all operands in LDS.
-template <int H>
-__device__ inline void inv_level(const double* __restrict__ L, double* __restrict__ X,
-                                 double* __restrict__ T, int tid) {
+template <int H, typename R>
+__device__ inline void inv_level(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
   constexpr int NPAIR = NB / (2 * H);
   constexpr int PER = H * H;
   for (int q = tid; q < NPAIR * PER; q += 256) {
     const int blk = q / PER, e = q % PER, i = e / H, c = e % H, o = blk * 2 * H;
-    double s = 0.0;
+    R s = 0;
 #pragma unroll 8
     for (int k = c; k < H; ++k) s += L[(o + H + i) * DS + o + k] * X[(o + k) * DS + o + c];
     T[(o + H + i) * DS + o + c] = s;
@@ -38,7 +51,7 @@ __device__ inline void inv_level(const double* __restrict__ L, double* __restric
   __syncthreads();
   for (int q = tid; q < NPAIR * PER; q += 256) {
     const int blk = q / PER, e = q % PER, i = e / H, c = e % H, o = blk * 2 * H;
-    double s = 0.0;
+    R s = 0;
 #pragma unroll 8
     for (int k = 0; k <= i; ++k) s += X[(o + H + i) * DS + o + H + k] * T[(o + H + k) * DS + o + c];
     X[(o + H + i) * DS + o + c] = -s;
@@ -49,48 +62,43 @@ __device__ inline void inv_level(const double* __restrict__ L, double* __restric
 // Register-tiled right-looking Cholesky of the 64x64 block: thread (ty, tx) of a 16 x 16 grid owns
 // rows 4 ty.., columns 4 tx.. in registers; per column one LDS broadcast of the pivot column and
 // ONE barrier (the column buffer is double-buffered).
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Kall,
-                                                         double* __restrict__ Mall,
-                                                         double* __restrict__ MTall,
+template <typename R>
+__global__ __launch_bounds__(256) void potrf_diag_kernel(R* __restrict__ Kall, R* __restrict__ Mall,
+                                                         R* __restrict__ MTall,
                                                          double* __restrict__ logdet,
                                                          int32_t* __restrict__ status,
                                                          int64_t Npad, int nblk, int slot0, int j0) {
-  __shared__ double L[NB * DS];
-  __shared__ double X[NB * DS];
-  __shared__ double T[NB * DS];
-  __shared__ double colbuf[2][NB];
+  __shared__ R L[NB * DS];
+  __shared__ R X[NB * DS];
+  __shared__ R T[NB * DS];
+  __shared__ R colbuf[2][NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
-  double* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
-  double* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  R* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  R* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   if (tid == 0) bad = 0;
-  double a[4][4];
+  R a[4][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double* src = K + (int64_t)(4 * ty + r) * Npad + 4 * tx;
-    double2 v01 = *reinterpret_cast<const double2*>(src);
-    double2 v23 = *reinterpret_cast<const double2*>(src + 2);
-    a[r][0] = v01.x; a[r][1] = v01.y; a[r][2] = v23.x; a[r][3] = v23.y;
-  }
-  for (int q = tid; q < NB * DS; q += 256) X[q] = 0.0;
+  for (int r = 0; r < 4; ++r) ld4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, a[r]);
+  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
   bool anybad = false;
   for (int jb = 0; jb < 16; ++jb) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = 4 * jb + jj;
-      double* cb = colbuf[j & 1];
+      R* cb = colbuf[j & 1];
       if (tx == jb && ty >= jb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cb[4 * ty + r] = a[r][jj];
       }
       __syncthreads();
-      double piv = cb[j];
-      const bool ok = piv > 0.0;  // false for NaN as well
-      if (!ok) { piv = 1.0; anybad = true; }
-      const double inv = rsqrt(piv);
+      R piv = cb[j];
+      const bool ok = piv > R(0);  // false for NaN as well
+      if (!ok) { piv = 1; anybad = true; }
+      const R inv = rsq(piv);
       if (ty >= tx && tx >= jb) {
-        double lr[4], lc[4];
+        R lr[4], lc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) lr[r] = cb[4 * ty + r] * inv;
 #pragma unroll
@@ -119,20 +127,16 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int i = 4 * ty + r, jc = 4 * tx + c;
-      const double v = (jc <= i) ? a[r][c] : 0.0;
+      const R v = (jc <= i) ? a[r][c] : R(0);
       a[r][c] = v;
       L[i * DS + jc] = v;
     }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double* dst = K + (int64_t)(4 * ty + r) * Npad + 4 * tx;
-    *reinterpret_cast<double2*>(dst) = make_double2(a[r][0], a[r][1]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(a[r][2], a[r][3]);
-  }
+  for (int r = 0; r < 4; ++r) st4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, a[r]);
   if (anybad && tid == 0) bad = 1;
   __syncthreads();
   if (tid < 64) {
-    double v = log(L[tid * DS + tid]);
+    double v = log((double)L[tid * DS + tid]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (tid == 0) {
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
   // ---- inverse of the lower-triangular block by recursive doubling ----
   if (tid < 64) {  // level 0: four 16x16 diagonal blocks, one thread per column
     const int blk = tid >> 4, c = tid & 15, o = blk * 16;
-    X[(o + c) * DS + o + c] = 1.0 / L[(o + c) * DS + o + c];
+    X[(o + c) * DS + o + c] = R(1) / L[(o + c) * DS + o + c];
     for (int i = c + 1; i < 16; ++i) {
-      double s = 0.0;
+      R s = 0;
       for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
       X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
     }
@@ -156,26 +160,28 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ka
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * ty + r;
-    double* dst = M + (int64_t)i * Npad + 4 * tx;
-    *reinterpret_cast<double2*>(dst) = make_double2(X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]);
+    const R v[4] = {X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1], X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]};
+    st4(M + (int64_t)i * Npad + 4 * tx, v);
   }
   if (MTall) {  // transposed image of the inverse block
-    double* MT = MTall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+    R* MT = MTall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * ty + r;
-      double* dst = MT + (int64_t)i * Npad + 4 * tx;
-      *reinterpret_cast<double2*>(dst) = make_double2(X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]);
+      const R v[4] = {X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i], X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]};
+      st4(MT + (int64_t)i * Npad + 4 * tx, v);
     }
   }
 }
 
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
   p.timer.begin(st, ST_POTRF_DIAG);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
-                     p.dstatus, p.Npad, p.nblk(), slot0, j0);
+  if (p.f32)
+    hipLaunchKernelGGL(potrf_diag_kernel<float>, dim3(nb), dim3(256), 0, st, p.Kbuf32, p.Mbuf32, p.MTbuf32,
+                       p.dlogdet, p.dstatus, p.Npad, p.nblk(), slot0, j0);
+  else
+    hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
+                       p.dstatus, p.Npad, p.nblk(), slot0, j0);
   p.timer.end(st);
 }
 
@@ -201,24 +207,25 @@ void launch_resid(Problem& p, hipStream_t st, int slot0, int nb) {
 }
 
 // z = M r  (M lower triangular). One wave per row, 4 rows per wave, 16 rows per workgroup.
-__global__ __launch_bounds__(256) void trmv_kernel(const double* __restrict__ Mall,
+template <typename R>
+__global__ __launch_bounds__(256) void trmv_kernel(const R* __restrict__ Mall,
                                                    const double* __restrict__ rall,
                                                    double* __restrict__ zall, int64_t Npad,
                                                    int slot0) {
   const int b = slot0 + blockIdx.y;
-  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const R* M = Mall + (int64_t)b * Npad * Npad;
   const double* r = rall + (int64_t)b * Npad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t i = (int64_t)blockIdx.x * 16 + wave * 4 + rr;
-    const double* row = M + i * Npad;
+    const R* row = M + i * Npad;
     double s = 0.0;
     const int64_t len = i + 1;  // columns 0..i
     for (int64_t j = 2 * lane; j < len; j += 128) {
-      double2 m = *reinterpret_cast<const double2*>(row + j);
+      const double m0 = (double)row[j], m1 = (double)row[j + 1];
       double2 v = *reinterpret_cast<const double2*>(r + j);
-      s += m.x * v.x;
-      if (j + 1 < len) s += m.y * v.y;
+      s += m0 * v.x;
+      if (j + 1 < len) s += m1 * v.y;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -227,19 +234,20 @@ __global__ __launch_bounds__(256) void trmv_kernel(const double* __restrict__ Ma
 }
 
 // alpha = M' z. Workgroup = 64 columns; wave w takes rows j0 + w, j0 + w + 4, ...
-__global__ __launch_bounds__(256) void trmv_t_kernel(const double* __restrict__ Mall,
+template <typename R>
+__global__ __launch_bounds__(256) void trmv_t_kernel(const R* __restrict__ Mall,
                                                      const double* __restrict__ zall,
                                                      double* __restrict__ aall, int64_t Npad,
                                                      int slot0) {
   __shared__ double red[4][64];
   const int b = slot0 + blockIdx.y;
-  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const R* M = Mall + (int64_t)b * Npad * Npad;
   const double* z = zall + (int64_t)b * Npad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
   double s = 0.0;
 #pragma unroll 4
-  for (int64_t i = j0 + wave; i < Npad; i += 4) s += M[i * Npad + j0 + lane] * z[i];
+  for (int64_t i = j0 + wave; i < Npad; i += 4) s += (double)M[i * Npad + j0 + lane] * z[i];
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0) aall[(int64_t)b * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
@@ -316,13 +324,23 @@ __global__ void alpha_reduce_kernel(const double* __restrict__ part, double* __r
 void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* in, double* out, int slot0,
                  int nb, bool trans) {
   if (!trans)
-    hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
+    hipLaunchKernelGGL(trmv_kernel<double>, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
   else
-    hipLaunchKernelGGL(trmv_t_kernel, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
+    hipLaunchKernelGGL(trmv_t_kernel<double>, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, Tmat, in, out, p.Npad, slot0);
 }
 
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha) {
   p.timer.begin(st, ST_SOLVE);
+  if (p.f32) {  // float32 storage: the two plain passes over M (float reads, float64 accumulation)
+    hipLaunchKernelGGL(trmv_kernel<float>, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf32, p.dr, p.dz,
+                       p.Npad, slot0);
+    if (need_alpha)
+      hipLaunchKernelGGL(trmv_t_kernel<float>, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, p.Mbuf32, p.dz,
+                         p.dalpha, p.Npad, slot0);
+    p.timer.end(st);
+    p.timer.work(ST_SOLVE, 0.0, (double)nb * 4.0 * (double)p.Npad * (p.Npad + 1) / 2.0 * (need_alpha ? 2 : 1));
+    return;
+  }
   if (need_alpha && p.dsolve_part && p.Npad <= 128 * TRMV_MAXC) {
     const int nrb = (int)(p.Npad / 64);
     hipLaunchKernelGGL(trmv_fused_kernel, dim3(nrb, nb), dim3(256), (size_t)4 * p.Npad * sizeof(double), st, p.Mbuf,
@@ -333,10 +351,10 @@ void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha
     p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + 1) / 2.0 + 2.0 * nrb * p.Npad / 2.0));
     return;
   }
-  hipLaunchKernelGGL(trmv_kernel, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
+  hipLaunchKernelGGL(trmv_kernel<double>, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
                      p.dz, p.Npad, slot0);
   if (need_alpha)
-    hipLaunchKernelGGL(trmv_t_kernel, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, p.Mbuf,
+    hipLaunchKernelGGL(trmv_t_kernel<double>, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, p.Mbuf,
                        p.dz, p.dalpha, p.Npad, slot0);
   p.timer.end(st);
   p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * (double)p.Npad * (p.Npad + 1) / 2.0 * (need_alpha ? 2 : 1));
@@ -401,8 +419,9 @@ void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad
 // ---------------------------------------------------------------------------------------
 // schedules
 // ---------------------------------------------------------------------------------------
-static GemmArgs base_args(const Problem& p, int slot0, int nb) {
-  GemmArgs a{};
+template <typename R = double>
+static GemmArgsT<R> base_args(const Problem& p, int slot0, int nb) {
+  GemmArgsT<R> a{};
   const int64_t mat = p.Npad * p.Npad;
   a.sA = a.sB = a.sC = mat;
   a.lda = a.ldb = a.ldc = (int)p.Npad;
@@ -508,6 +527,7 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 //   M21 = -M22 T                      (contraction k <= row)
 // L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
 // ---------------------------------------------------------------------------------------
+template <typename R>
 static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
   if (n == NB) {
     launch_potrf_diag(p, st, slot0, nb, (int)o);
@@ -515,14 +535,15 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   }
   const int64_t Np = p.Npad, mat = Np * Np;
   const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
-  double* K0 = p.Kbuf + (int64_t)slot0 * mat;
-  double* M0 = p.Mbuf + (int64_t)slot0 * mat;
-  double* MT0 = p.MTbuf + (int64_t)slot0 * mat;
-  double* S0 = p.Pbuf + (int64_t)slot0 * p.pbuf_elems();  // holds S' (h1 x h2): K-strided image of S
+  const MatBufs<R> mb = mat_bufs<R>(p);
+  R* K0 = mb.K + (int64_t)slot0 * mat;
+  R* M0 = mb.M + (int64_t)slot0 * mat;
+  R* MT0 = mb.MT + (int64_t)slot0 * mat;
+  R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();  // holds S' (h1 x h2): K-strided image of S
   const int64_t sS = p.pbuf_elems();
-  fi_node(p, st, slot0, nb, o, h1);
+  fi_node<R>(p, st, slot0, nb, o, h1);
   {  // S = A21 * M11'   written transposed;  B(n, k) = M11[n][k] = MT[k][n]  (K-strided)
-    GemmArgs a = base_args(p, slot0, nb);
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = K0 + (o + h1) * Np + o;
     a.B = MT0 + o * Np + o;
     a.C = nullptr;
@@ -534,7 +555,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
   {  // A22 -= S S'   with A(m, k) = S'[k][m], B(n, k) = S'[k][n]
-    GemmArgs a = base_args(p, slot0, nb);
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h2;
     a.C = K0 + (o + h1) * Np + (o + h1);
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
@@ -545,7 +566,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
   {  // T = S * M11 over the dead A21 block;  A(m, k) = S'[k][m],  B(n, k) = M11[k][n]
-    GemmArgs a = base_args(p, slot0, nb);
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = S0; a.sA = sS; a.lda = (int)h2;
     a.B = M0 + o * Np + o;
     a.C = K0 + (o + h1) * Np + o;
@@ -555,9 +576,9 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
-  fi_node(p, st, slot0, nb, o + h1, h2);
+  fi_node<R>(p, st, slot0, nb, o + h1, h2);
   {  // M21 = -M22 * T  (also written transposed into MT);  A(m, k) = M22[m][k] = MT[k][m]
-    GemmArgs a = base_args(p, slot0, nb);
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = MT0 + (o + h1) * Np + (o + h1);
     a.B = K0 + (o + h1) * Np + o;  // B(n, k) = T[k][n]
     a.C = M0 + (o + h1) * Np + o;
@@ -571,21 +592,29 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
 }
 
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb) {
-  fi_node(p, st, slot0, nb, 0, p.Npad);
+  if (p.f32) fi_node<float>(p, st, slot0, nb, 0, p.Npad);
+  else fi_node<double>(p, st, slot0, nb, 0, p.Npad);
 }
 
-void lauum(Problem& p, hipStream_t st, int slot0, int nb) {
+template <typename R>
+static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   const int64_t Np = p.Npad, mat = Np * Np;
-  GemmArgs a = base_args(p, slot0, nb);
-  a.A = p.Mbuf + (int64_t)slot0 * mat;  // A(m, l) = M[l][m]
-  a.B = p.Mbuf + (int64_t)slot0 * mat;  // B(n, l) = M[l][n]
-  a.C = p.Kbuf + (int64_t)slot0 * mat;
+  const MatBufs<R> mb = mat_bufs<R>(p);
+  GemmArgsT<R> a = base_args<R>(p, slot0, nb);
+  a.A = mb.M + (int64_t)slot0 * mat;  // A(m, l) = M[l][m]
+  a.B = mb.M + (int64_t)slot0 * mat;  // B(n, l) = M[l][n]
+  a.C = mb.K + (int64_t)slot0 * mat;
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
   p.timer.begin(st, ST_LAUUM);
   launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
   p.timer.end(st);
   p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
+}
+
+void lauum(Problem& p, hipStream_t st, int slot0, int nb) {
+  if (p.f32) lauum_t<float>(p, st, slot0, nb);
+  else lauum_t<double>(p, st, slot0, nb);
 }
 
 }  // namespace wv

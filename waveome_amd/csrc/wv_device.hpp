@@ -57,10 +57,11 @@ struct DevSpec {
 // ---- GEMM launch description --------------------------------------------------------
 // C[m][n] = beta*C[m][n] + alpha * sum_{k in [kb,ke)} A(m,k) * B(n,k),  per batch slot.
 // A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m];  B(n,k) likewise.
-struct GemmArgs {
-  const double* A;
-  const double* B;
-  double* C;
+template <typename T>
+struct GemmArgsT {
+  const T* A;
+  const T* B;
+  T* C;
   int64_t sA, sB, sC;  // batch strides (elements)
   int32_t lda, ldb, ldc;
   int32_t M, N;        // extent of C
@@ -74,7 +75,7 @@ struct GemmArgs {
   double alpha, beta;
   int32_t nbatch;
   int32_t tiles_m, tiles_n;
-  double* CT;          // transposed output (tout != 0): CT[n][m], batch stride sCT, leading dimension ldct
+  T* CT;               // transposed output (tout != 0): CT[n][m], batch stride sCT, leading dimension ldct
   int64_t sCT;
   int32_t ldct, tout;
   int32_t tag;         // 1: launch the separately named instantiation (K_y^-1 = M'M)
@@ -82,6 +83,8 @@ struct GemmArgs {
   int32_t latin;
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
 };
+using GemmArgs = GemmArgsT<double>;
+using GemmArgsF = GemmArgsT<float>;  // float32 storage path (wv_gemm32.hip)
 
 enum Stage {
   ST_GRAM = 0, ST_POTRF_DIAG, ST_CHOL_TRSM, ST_CHOL_PANEL, ST_CHOL_TRAIL, ST_TRTRI_A, ST_TRTRI_B,
@@ -110,6 +113,7 @@ struct StageTimer {
 
 struct Ctx {
   int device = 0;
+  int dtype = 0;  // 0: float64 matrices, 1: float32 matrices (vectors, reductions and host I/O stay float64)
   hipDeviceProp_t prop;
 };
 
@@ -136,6 +140,9 @@ struct Problem {
   double *dX = nullptr, *dY = nullptr;
   DevSpec* dspec = nullptr;
   double *Kbuf = nullptr, *Mbuf = nullptr, *MTbuf = nullptr, *Pbuf = nullptr;
+  // float32 problems (ctx dtype 1) keep the four N x N work matrices in these instead
+  int f32 = 0;
+  float *Kbuf32 = nullptr, *Mbuf32 = nullptr, *MTbuf32 = nullptr, *Pbuf32 = nullptr;
   double *dtheta = nullptr, *dr = nullptr, *dz = nullptr, *dalpha = nullptr;
   double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
@@ -162,6 +169,7 @@ void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* i
                  int nb, bool trans);
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0);
 void launch_gemm(hipStream_t st, const GemmArgs& a, bool a_kcontig, bool b_kcontig, int bn);
+void launch_gemm(hipStream_t st, const GemmArgsF& a, bool a_kcontig, bool b_kcontig, int bn);
 void launch_resid(Problem& p, hipStream_t st, int slot0, int nb);
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha);
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb);
@@ -173,6 +181,29 @@ void cholesky(Problem& p, hipStream_t st, int slot0, int nb);
 void trtri(Problem& p, hipStream_t st, int slot0, int nb);
 void lauum(Problem& p, hipStream_t st, int slot0, int nb);
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb);  // recursive potrf + trtri
+
+// the N x N work matrices of a problem in their storage type
+template <typename T> struct MatBufs { T *K, *M, *MT, *P; };
+template <typename T> inline MatBufs<T> mat_bufs(Problem& p);
+template <> inline MatBufs<double> mat_bufs<double>(Problem& p) { return {p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf}; }
+template <> inline MatBufs<float> mat_bufs<float>(Problem& p) { return {p.Kbuf32, p.Mbuf32, p.MTbuf32, p.Pbuf32}; }
+
+// 4 consecutive matrix elements <-> 4 doubles (16-byte aligned in float32, two 16-byte halves in float64)
+__device__ inline void load4(const double* __restrict__ src, double (&v)[4]) {
+  const double2 a = *reinterpret_cast<const double2*>(src), b = *reinterpret_cast<const double2*>(src + 2);
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ inline void load4(const float* __restrict__ src, double (&v)[4]) {
+  const float4 a = *reinterpret_cast<const float4*>(src);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ inline void store4(double* __restrict__ dst, const double (&v)[4]) {
+  *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+  *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+}
+__device__ inline void store4(float* __restrict__ dst, const double (&v)[4]) {
+  *reinterpret_cast<float4*>(dst) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
 
 std::string build_devspec(const Spec& s, DevSpec& out);
 

@@ -1,0 +1,288 @@
+// Batched float32 GEMM family on v_mfma_f32_16x16x4_f32 (gfx950): the float32-storage twin of
+// wv_gemm.hip, serving the same products of the factor-and-invert schedule (wv_chol.hip) when a
+// problem was created on a float32 context (the reference's `set_precision("float32")`,
+// waveome/utilities.py:34-49; BASELINE config C5).  Same GemmArgs semantics: per-tile contraction
+// trimming (klo_mode / khi_mode), lower-only tile enumeration (tri), Latin-square skew of the tile
+// order, transposed outputs (tout), K walked downwards for tiles trimmed from below.
+//
+// v_mfma_f32_16x16x4_f32: 8 passes (32 cycles), 2048 FLOP -> 256 FLOP / clk / CU, the dense fp32
+// matrix rate (157 TFLOP/s at 2.4 GHz).  Lane maps (lane l, fr = l & 15, fk = l >> 4):
+//   A: lane holds A[row fr][k fk]      B: lane holds B[k fk][col fr]
+//   D: register r of lane holds D[row 4 fk + r][col fr]
+// i.e. the operand fragments are the ones the float64 kernel reads (row l & 15, k = l >> 4), one MFMA
+// covers the whole 16 x 16 block, so there is no rotation of B fragments.
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 (4 x 4 MFMA blocks,
+// 64 accumulator VGPRs), K chunk 32, global -> registers -> LDS double-buffered, one barrier per chunk.
+// LDS images, conflict-free for the ds_read_b32 fragment reads (64 lanes = 16 rows x 4 k):
+//   K-contiguous operand  [rows][32 + 4]   row stride 36 floats: 36 r mod 64 = the 16 multiples of 4
+//   K-strided   operand   [32][rows + 16]  row stride 144 floats = 16 mod 64
+// B is always K-strided (every product of the schedule reads B by rows of K).
+#include <cstdio>
+#include <cstdlib>
+
+#include "wv_device.hpp"
+
+namespace wv {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace g32 {
+constexpr int BM = 128, BN = 128, KC = 32;
+
+template <bool KCONTIG>
+struct Tile {
+  static constexpr int ROWS = 128;
+  static constexpr int LD = KCONTIG ? (KC + 4) : (ROWS + 16);
+  static constexpr int SIZE = KCONTIG ? ROWS * LD : KC * LD;
+  static constexpr int NLOAD = ROWS * KC / 4 / 256;  // float4 loads per thread per chunk (= 4)
+  __device__ static inline int at(int row, int k) { return KCONTIG ? row * LD + k : k * LD + row; }
+
+  __device__ static inline void gload(f4 (&reg)[NLOAD], const float* __restrict__ base, int ld, int row0,
+                                      int nrows, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int q = tid + 256 * i;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (KCONTIG) {
+        const int row = q >> 3, kp = q & 7;
+        if (row0 + row < nrows) v = *reinterpret_cast<const f4*>(base + (int64_t)(row0 + row) * ld + k0 + 4 * kp);
+      } else {
+        const int k = q >> 5, rp = q & 31;
+        if (row0 + 4 * rp < nrows) v = *reinterpret_cast<const f4*>(base + (int64_t)(k0 + k) * ld + row0 + 4 * rp);
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ static inline void sstore(float* __restrict__ s, const f4 (&reg)[NLOAD], int tid) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int q = tid + 256 * i;
+      if (KCONTIG) {
+        const int row = q >> 3, kp = q & 7;
+        *reinterpret_cast<f4*>(s + row * LD + 4 * kp) = reg[i];
+      } else {
+        const int k = q >> 5, rp = q & 31;
+        *reinterpret_cast<f4*>(s + k * LD + 4 * rp) = reg[i];
+      }
+    }
+  }
+};
+}  // namespace g32
+
+// TOUT: 0 = write C; 1 = write only C' (g.CT, leading dimension g.ldct); 2 = both.  TAG = 1 gives the
+// K_y^-1 = M'M launch its own symbol for profilers.
+template <bool A_KC, int TOUT, int TAG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
+  using namespace g32;
+  using TA = Tile<A_KC>;
+  using TB = Tile<false>;
+  constexpr int LDC = BN + 4;  // epilogue staging image [64][LDC] of half the C tile
+  constexpr int SMEM = 2 * (TA::SIZE + TB::SIZE) > 64 * LDC ? 2 * (TA::SIZE + TB::SIZE) : 64 * LDC;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float(*sA)[TA::SIZE] = reinterpret_cast<float(*)[TA::SIZE]>(smem);
+  float(*sB)[TB::SIZE] = reinterpret_cast<float(*)[TB::SIZE]>(smem + 2 * TA::SIZE);
+
+  // ---- block -> (batch, tile): same-matrix tiles on one XCD when there are >= 8 matrices ----
+  const int tiles = g.tiles_live;
+  int b, tile;
+  if (g.nbatch >= 8) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    b = xcd + 8 * (q / tiles);
+    tile = q % tiles;
+    if (b >= g.nbatch) return;
+  } else {
+    b = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  if (g.khi_mode && !g.tri) tile = tiles - 1 - tile;  // longest contraction first
+  int tm, tn;
+  if (g.tri) {
+    tm = 0;
+    for (;;) {
+      const int cnt = min(g.tiles_n, max(0, (tm * BM + BM - 1 - g.tri_off) / BN + 1));
+      if (tile < cnt) break;
+      tile -= cnt;
+      ++tm;
+    }
+    tn = tile;
+  } else {
+    tm = tile / g.tiles_n;
+    tn = tile % g.tiles_n;
+    // column-dependent contraction lengths: Latin-square skew (see wv_gemm.hip)
+    if (g.khi_mode == 2 || g.klo_mode == 2) tn = (tn + tm) % g.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int kb = g.kb, ke = g.ke;
+  if (g.klo_mode == 1) kb = max(kb, m0 + g.koff);
+  if (g.klo_mode == 2) kb = max(kb, n0 + g.koff);
+  if (g.khi_mode == 1) ke = min(ke, m0 + BM + g.koff);
+  if (g.khi_mode == 2) ke = min(ke, n0 + BN + g.koff);
+  // chunks are 32 wide while operand extents are multiples of 64: round the range outwards onto the
+  // chunk grid anchored at g.kb (the extra rows are zeros of the triangular operand or inside [g.kb, g.ke))
+  kb = g.kb + (kb - g.kb) / KC * KC;
+  ke = min(g.ke, g.kb + (ke - g.kb + KC - 1) / KC * KC);
+
+  const float* __restrict__ A = g.A + (int64_t)b * g.sA;
+  const float* __restrict__ B = g.B + (int64_t)b * g.sB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // per-wave contraction range at 64-row / 64-column granularity (triangular operands, lower-only products)
+  int wkb = kb, wke = ke;
+  {
+    const int wr = m0 + wm * 64, wc = n0 + wn * 64;
+    if (g.klo_mode == 1) wkb = max(wkb, wr + g.koff);
+    if (g.klo_mode == 2) wkb = max(wkb, wc + g.koff);
+    if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
+    if (g.khi_mode == 2) wke = min(wke, wc + 64 + g.koff);
+    if (g.tri && wc + g.tri_off > wr + 63) wke = wkb;
+  }
+  f4 ra[TA::NLOAD], rb[TB::NLOAD];
+  const int nchunk = (ke - kb + KC - 1) / KC;
+  const int kstep = g.klo_mode ? -KC : KC;  // tiles trimmed from below walk K downwards from the common end
+  kb = g.klo_mode ? ke - KC : kb;
+  if (nchunk > 0) {
+    TA::gload(ra, A, g.lda, m0, g.M, kb, tid);
+    TB::gload(rb, B, g.ldb, n0, g.N, kb, tid);
+    TA::sstore(sA[0], ra, tid);
+    TB::sstore(sB[0], rb, tid);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunk) {
+      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, tid);
+      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, tid);
+    }
+    const float* __restrict__ a_s = sA[cur];
+    const float* __restrict__ b_s = sB[cur];
+    const int kc0 = kb + c * kstep;
+    if (kc0 + KC > wkb && kc0 < wke) {
+#pragma unroll 2
+      for (int s = 0; s < KC / 4; ++s) {
+        float af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = b_s[TB::at(wn * 64 + j * 16 + fr, s * 4 + fk)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunk) {
+      TA::sstore(sA[cur ^ 1], ra, tid);
+      TB::sstore(sB[cur ^ 1], rb, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C = beta C + alpha acc, staged through LDS so that C moves as full rows ----
+  float* __restrict__ C = g.C + (int64_t)b * g.sC;
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+  constexpr int QUADS = BN / 4;             // float4 per row
+  constexpr int NROWIT = 64 * QUADS / 256;  // = 8
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f4 cv[NROWIT];
+    if (TOUT != 1 && beta != 0.f) {
+#pragma unroll
+      for (int it = 0; it < NROWIT; ++it) {
+        const int q = tid + 256 * it, row = q / QUADS, cp = q % QUADS;
+        const int m = m0 + 64 * h + row, n = n0 + 4 * cp;
+        cv[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const f4*>(C + (int64_t)m * g.ldc + n) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            smem[(i * 16 + 4 * fk + r) * LDC + wn * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+    }
+    __syncthreads();
+    if (TOUT != 1) {
+#pragma unroll
+      for (int it = 0; it < NROWIT; ++it) {
+        const int q = tid + 256 * it, row = q / QUADS, cp = q % QUADS;
+        const int m = m0 + 64 * h + row, n = n0 + 4 * cp;
+        if (m < g.M && n < g.N) {
+          f4 v = *reinterpret_cast<const f4*>(smem + row * LDC + 4 * cp);
+          if (beta != 0.f) v += beta * cv[it];
+          *reinterpret_cast<f4*>(C + (int64_t)m * g.ldc + n) = v;
+        }
+      }
+    }
+    if (TOUT != 0) {
+      // transposed copy: thread -> (column n, 4 consecutive rows), 16 lanes x 16 B per row of C'
+      float* __restrict__ CT = g.CT + (int64_t)b * g.sCT;
+#pragma unroll
+      for (int it = 0; it < NROWIT; ++it) {
+        const int q = tid + 256 * it, n = q >> 4, mp = q & 15;
+        const int m = m0 + 64 * h + 4 * mp, nn = n0 + n;
+        if (m < g.M && nn < g.N) {
+          f4 v;
+          v.x = smem[(4 * mp) * LDC + n];
+          v.y = smem[(4 * mp + 1) * LDC + n];
+          v.z = smem[(4 * mp + 2) * LDC + n];
+          v.w = smem[(4 * mp + 3) * LDC + n];
+          *reinterpret_cast<f4*>(CT + (int64_t)nn * g.ldct + m) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_gemm(hipStream_t st, const GemmArgsF& a_in, bool a_kc, bool b_kc, int /*bn*/) {
+  using namespace g32;
+  GemmArgsF a = a_in;
+  if (b_kc) {
+    fprintf(stderr, "launch_gemm(float32): K-contiguous B is not used by the schedule and not built\n");
+    abort();
+  }
+  if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  int tiles = a.tiles_m * a.tiles_n;
+  if (a.tri) {
+    tiles = 0;
+    for (int tm = 0; tm < a.tiles_m; ++tm)
+      tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / BN + 1));
+  }
+  a.tiles_live = tiles;
+  a.latin = 1;
+  a.rot_tri = 0;
+  if (tiles <= 0) return;
+  const int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
+  dim3 g(grid), blk(256);
+  if (a.tag == 1 && !a_kc && a.tout == 0) {
+    hipLaunchKernelGGL((gemm_f32_kernel<false, 0, 1>), g, blk, 0, st, a);
+  } else if (a.tout == 0) {
+    if (a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, 0>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, 0>), g, blk, 0, st, a);
+  } else if (a.tout == 1 && a_kc) {
+    hipLaunchKernelGGL((gemm_f32_kernel<true, 1>), g, blk, 0, st, a);
+  } else if (a.tout == 2 && !a_kc) {
+    hipLaunchKernelGGL((gemm_f32_kernel<false, 2>), g, blk, 0, st, a);
+  } else {
+    fprintf(stderr, "launch_gemm(float32): unsupported transposed-output variant\n");
+    abort();
+  }
+}
+
+}  // namespace wv

@@ -256,17 +256,18 @@ __device__ inline void tri_decode(int t, int& ti, int& tj) {
   tj = t - i * (i + 1) / 2;
 }
 
+template <typename R>
 __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ sp,
                                                    const double* __restrict__ X,
                                                    const double* __restrict__ theta_all,
-                                                   double* __restrict__ Kall, int64_t N,
+                                                   R* __restrict__ Kall, int64_t N,
                                                    int64_t Npad, int D, int slot0, int write_upper,
                                                    uint64_t term_mask, double diag_override) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const int16_t* slots = sp->fslots;
   const double* th = theta_all + (int64_t)b * sp->n_params;
-  double* K = Kall + (int64_t)b * Npad * Npad;
+  R* K = Kall + (int64_t)b * Npad * Npad;
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   const int tid = threadIdx.x;
@@ -310,12 +311,10 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
       if (i >= N || j >= N) x = (i == j) ? 1.0 : 0.0;  // identity padding
       v[c] = x;
     }
-    double* dst = K + i * Npad + (int64_t)tj * GT + 4 * t.tx;
-    *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+    store4(K + i * Npad + (int64_t)tj * GT + 4 * t.tx, v);
     if (write_upper && ti != tj) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) K[((int64_t)tj * GT + 4 * t.tx + c) * Npad + i] = v[c];
+      for (int c = 0; c < 4; ++c) K[((int64_t)tj * GT + 4 * t.tx + c) * Npad + i] = (R)v[c];
     }
   }
 }
@@ -391,10 +390,11 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 
 // part[b][wg][p] = sum over this workgroup's tiles of  w_ij W_ij dK_ij/dtheta_p
 // (w = 1 below the diagonal, 1/2 on it, 0 above; noise_param gets 1/2 W_ii).
+template <typename R>
 __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ sp,
                                                     const double* __restrict__ X,
                                                     const double* __restrict__ theta_all,
-                                                    const double* __restrict__ Kinv_all,
+                                                    const R* __restrict__ Kinv_all,
                                                     const double* __restrict__ alpha_all,
                                                     double* __restrict__ part, int64_t N,
                                                     int64_t Npad, int D, int slot0, int ntiles,
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
   const int16_t* slots = sp->fslots;
   const int np = sp->n_params;
   const double* th = theta_all + (int64_t)b * np;
-  const double* Kinv = Kinv_all + (int64_t)b * Npad * Npad;
+  const R* Kinv = Kinv_all + (int64_t)b * Npad * Npad;
   const double* alpha = alpha_all + (int64_t)b * Npad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* fi = smem;
@@ -433,10 +433,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
     for (int a = 0; a < 4; ++a) {
       const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
       const double ai = alpha[i];
-      const double* src = Kinv + i * Npad + (int64_t)tj * GT + 4 * t.tx;
-      double2 k01 = *reinterpret_cast<const double2*>(src);
-      double2 k23 = *reinterpret_cast<const double2*>(src + 2);
-      double kv[4] = {k01.x, k01.y, k23.x, k23.y};
+      double kv[4];
+      load4(Kinv + i * Npad + (int64_t)tj * GT + 4 * t.tx, kv);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
@@ -487,18 +485,26 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
   dim3 grid(p.ntiles(), nb), blk(256);
   size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
-  hipLaunchKernelGGL(gram_kernel, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D, slot0,
-                     0, term_mask, diag);
+  if (p.f32)
+    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad, p.D,
+                       slot0, 0, term_mask, diag);
+  else
+    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D,
+                       slot0, 0, term_mask, diag);
 }
 
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper) {
   dim3 grid(p.ntiles(), nb), blk(256);
   size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
   p.timer.begin(st, ST_GRAM);
-  hipLaunchKernelGGL(gram_kernel, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
-                     p.D, slot0, write_upper, ~0ull, -1.0);
+  if (p.f32)
+    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad,
+                       p.D, slot0, write_upper, ~0ull, -1.0);
+  else
+    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
+                       p.D, slot0, write_upper, ~0ull, -1.0);
   p.timer.end(st);
-  p.timer.work(ST_GRAM, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
+  p.timer.work(ST_GRAM, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
 
 int trace_nwg(const Problem& p) { return (p.ntiles() + TRACE_TPW - 1) / TRACE_TPW; }
@@ -508,10 +514,14 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   dim3 grid(nwg, nb), blk(256);
   size_t sh = ((size_t)2 * p.hspec.n_feat * GT + 4 * p.hspec.n_params) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
-  hipLaunchKernelGGL(trace_kernel, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.dalpha,
-                     p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
+  if (p.f32)
+    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.dalpha,
+                       p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
+  else
+    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.dalpha,
+                       p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
   p.timer.end(st);
-  p.timer.work(ST_TRACE, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
+  p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
 
 }  // namespace wv

@@ -23,11 +23,19 @@ def lbfgs_opts(maxiter=50000, maxfun=None, ftol=2.220446049250313e-09, gtol=1e-0
 
 
 class Context:
-    def __init__(self, device: int = 0):
+    """One per GPU and precision.  dtype "float64" (default) or "float32": the storage / MFMA type of the
+    N x N work matrices - the reference's `set_precision` (waveome/utilities.py:34-49); parameters, vectors,
+    reductions and every host-side number stay float64."""
+
+    def __init__(self, device: int = 0, dtype: str = "float64"):
+        if dtype not in ("float64", "float32"):
+            raise ValueError("Precision must be either 'float32' or 'float64'")
         self.lib = _lib.load()
         self.handle = C.c_void_p()
-        _lib.check(self.lib.wv_ctx_create(int(device), 0, C.byref(self.handle)), "wv_ctx_create")
+        _lib.check(self.lib.wv_ctx_create(int(device), 1 if dtype == "float32" else 0, C.byref(self.handle)),
+                   "wv_ctx_create")
         self.device = int(device)
+        self.dtype = dtype
 
     def close(self):
         if self.handle:

@@ -26,9 +26,11 @@ _default_ctx: Optional[Context] = None
 
 
 def default_context(device: int = 0) -> Context:
+    from .utilities import get_precision
+
     global _default_ctx
-    if _default_ctx is None or _default_ctx.device != device:
-        _default_ctx = Context(device)
+    if _default_ctx is None or _default_ctx.device != device or _default_ctx.dtype != get_precision():
+        _default_ctx = Context(device, dtype=get_precision())
     return _default_ctx
 
 

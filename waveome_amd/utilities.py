@@ -10,6 +10,22 @@ import numpy as np
 from . import kernels as K
 
 
+_precision = "float64"
+
+
+def set_precision(precision: str = "float64"):
+    """Default floating point precision of contexts created afterwards (waveome/utilities.py:34-49):
+    "float32" keeps the N x N work matrices and their MFMA products in float32."""
+    global _precision
+    if precision not in ["float32", "float64"]:
+        raise ValueError("Precision must be either 'float32' or 'float64'")
+    _precision = precision
+
+
+def get_precision():
+    return _precision
+
+
 def calc_bic(loglik: float, n: int, k: int):
     """2k - 2 loglik (the reference's 'BIC' does not use log n, waveome/utilities.py:94-95)."""
     return 2 * k - 2 * loglik
