@@ -159,7 +159,11 @@ void wv_lbfgs_destroy(wv_lbfgs* s);
 /* ---- device path ------------------------------------------------------ */
 
 int32_t wv_device_count(int32_t* count_out);
-/* One context per GPU / process.  dtype: 0 = float64 (only value supported in ABI v1). */
+/* One context per GPU, process and precision.  dtype: 0 = float64; 1 = float32 storage and MFMA products
+ * for the N x N work matrices of problems created on this context - the reference's
+ * set_precision("float32") (waveome/utilities.py:34-49).  Parameters, X, Y, vectors, reductions and
+ * every number crossing this ABI stay float64.  wv_predict / wv_whitened_means are float64-only
+ * (WV_E_UNSUPPORTED on a float32 problem). */
 int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out);
 void wv_ctx_destroy(wv_ctx* ctx);
 /* Block until all work queued on this context's GPU has finished (hipDeviceSynchronize). */
