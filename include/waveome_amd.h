@@ -217,6 +217,23 @@ int32_t wv_fit_penalized(wv_problem* prob, const int32_t* col_idx, int32_t n_tas
                          double* loss_out, double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out,
                          int32_t* status_out);
 
+/* Several kernel structures on the same (X, Y): one workspace and ONE work queue for tasks that differ in
+ * structure as well as in column - the "Y columns x candidate kernel structures" sweep that the reference
+ * runs as one kernel_test per candidate (waveome/model_search.py:2239-2334, 2347-2558) and one Ray task
+ * per output (:1200-1222).  Every batch slot carries its task's structure index, so a launch mixes
+ * structures freely; only the Gram assembly and the gradient trace read the structure.
+ * wv_fit_multi: spec_idx[t] selects the structure of task t; theta_u_inout is n_tasks x u_stride
+ * (u_stride >= the largest number of trainable parameters; a task uses the first n_trainable of its row).
+ * A multi-structure problem is served by wv_fit_multi only (the single-structure entry points answer
+ * WV_E_UNSUPPORTED / WV_E_BADARG). */
+int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
+                                const wv_kernel_spec* const* specs, int32_t n_specs, int32_t max_batch,
+                                int32_t x_is_device, int32_t y_is_device, wv_problem** out);
+int32_t wv_fit_multi(wv_problem* prob, const int32_t* col_idx, const int32_t* spec_idx, int32_t n_tasks,
+                     const wv_lbfgs_opts* opts, const double* prior_scale, int32_t u_stride,
+                     double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
+                     int32_t* n_eval_out, int32_t* status_out);
+
 /* Posterior prediction for ONE task at constrained table theta: mean and variance of f (and of
  * y = f + noise when include_noise != 0).  Replaces predict_f / predict_y
  * (waveome/model_classes.py:526-544) for the exact GP.  Xnew = NULL: the N training inputs

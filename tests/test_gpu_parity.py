@@ -623,3 +623,37 @@ def test_results_do_not_depend_on_batch_composition(ctx):
     np.testing.assert_array_equal(fit_big["loss"], fit_small["loss"])
     big.close()
     small.close()
+
+
+def test_multi_structure_fit_equals_per_structure_fits(ctx):
+    """wv_fit_multi: tasks of different kernel structures in one work queue give bit-identical results to
+    fitting each structure in its own problem (a slot's arithmetic does not depend on its neighbours)."""
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(21, 150, D=4, P=3)
+    kerns = [K.SquaredExponential(active_dims=[0]),
+             K.Sum([K.Matern32(active_dims=[1]), K.Lin(active_dims=[2])]),
+             K.Sum([K.Categorical(active_dims=[3]), K.Periodic(K.SquaredExponential(active_dims=[0])),
+                    K.Product([K.Categorical(active_dims=[3]), K.SquaredExponential(active_dims=[1])])])]
+    specs = [ModelSpec(k, 4, K.GaussianLikelihood(), K.ConstantMean()) for k in kerns]
+    opts = lbfgs_opts(maxiter=40)
+    cols = np.array([0, 1, 2, 0, 1, 2, 1], dtype=np.int32)
+    sidx = np.array([0, 1, 2, 2, 0, 1, 1], dtype=np.int32)
+    width = max(sp.n_trainable for sp in specs)
+    U0 = np.zeros((len(cols), width + 2))  # a wider row than needed is allowed
+    for t, si in enumerate(sidx):
+        U0[t, :specs[si].n_trainable] = specs[si].unconstrain()
+    multi = Problem(ctx, X, Y, specs, max_batch=4)
+    rm = multi.fit_multi(cols, sidx, U0, opts)
+    with pytest.raises(Exception, match="several structures"):
+        multi.lml(cols[:1], specs[0].theta()[None, :])
+    multi.close()
+    for si, sp in enumerate(specs):
+        sel = np.nonzero(sidx == si)[0]
+        single = Problem(ctx, X, Y, sp, max_batch=2)
+        rs = single.fit(cols[sel], U0[sel, :sp.n_trainable], opts)
+        single.close()
+        for key in ("loss", "lml", "nit", "nfev", "status"):
+            np.testing.assert_array_equal(rm[key][sel], rs[key])
+        np.testing.assert_array_equal(rm["u"][sel, :sp.n_trainable], rs["u"])
+        assert np.all(np.isnan(rm["u"][sel, sp.n_trainable:]))

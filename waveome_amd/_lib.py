@@ -74,6 +74,9 @@ SIGNATURES = {
     "wv_problem_create": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32,
                                       C.POINTER(KernelSpec), C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(_vp)]),
+    "wv_problem_create_multi": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32,
+                                            C.POINTER(C.POINTER(KernelSpec)), C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.POINTER(_vp)]),
     "wv_problem_destroy": (None, [_vp]),
     "wv_problem_workspace_bytes": (C.c_int64, [_vp]),
     "wv_gram": (C.c_int32, [_vp, _dp, _dp]),
@@ -81,6 +84,8 @@ SIGNATURES = {
     "wv_value_grad": (C.c_int32, [_vp, _ip, C.c_int32, _dp, _dp, _dp, _ip]),
     "wv_fit": (C.c_int32, [_vp, _ip, C.c_int32, C.POINTER(LbfgsOpts), _dp, _dp, _dp, _ip, _ip, _ip]),
     "wv_fit_penalized": (C.c_int32, [_vp, _ip, C.c_int32, C.POINTER(LbfgsOpts), _dp, _dp, _dp, _dp, _ip, _ip, _ip]),
+    "wv_fit_multi": (C.c_int32, [_vp, _ip, _ip, C.c_int32, C.POINTER(LbfgsOpts), _dp, C.c_int32, _dp, _dp, _dp, _ip,
+                                 _ip, _ip]),
     "wv_predict": (C.c_int32, [_vp, C.c_int32, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp]),
     "wv_whitened_means": (C.c_int32, [_vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.c_int32, C.c_double, _dp]),
     "wv_stage_times": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_char_p), _dp,

@@ -132,10 +132,12 @@ std::string build_devspec(const Spec& s, DevSpec& d) {
 // group's pinned h_out / h_status when g.done fires.
 static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
   hipStream_t st = g.stream;
-  const int np = p.spec.n_params();
+  const int np = p.np_stride;
   WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np, g.h_theta, sizeof(double) * np * nb,
                             hipMemcpyHostToDevice, st));
   WV_HIP_TRY(hipMemcpyAsync(p.dcol + g.slot0, g.h_col, sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
+  if (p.specs.size() > 1)  // (single-structure problems keep the all-zero table written at creation)
+    WV_HIP_TRY(hipMemcpyAsync(p.dslotspec + g.slot0, g.h_spec, sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
   launch_resid(p, st, g.slot0, nb);
   launch_gram(p, st, g.slot0, nb, 0);
   static const bool old_sched = std::getenv("WV_SCHED_OLD") != nullptr;
@@ -167,10 +169,9 @@ static int wait_group(Problem& p, Group& g) {
 }
 
 // loss = -(LML + log prior), gradient w.r.t. unconstrained trainables, from a result record
-static void loss_from_record(const Problem& p, const double* u, const double* theta, const double* rec,
+static void loss_from_record(const Spec& s, const double* u, const double* theta, const double* rec,
                              int status, double* loss, double* grad_u, double* lml_out,
                              double prior_scale = -1.0) {
-  const Spec& s = p.spec;
   const int nt = s.n_trainable();
   double lml = rec[0];
   bool ok = status == 0 && std::isfinite(lml);
@@ -274,9 +275,10 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_col) hipHostFree(g.h_col);
     if (g.h_out) hipHostFree(g.h_out);
     if (g.h_status) hipHostFree(g.h_status);
+    if (g.h_spec) hipHostFree(g.h_spec);
   }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
-                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.Kbuf32, p.Mbuf32, p.MTbuf32,
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.Kbuf32, p.Mbuf32, p.MTbuf32,
                   p.Pbuf32};
   for (void* q : ptrs)
     if (q) hipFree(q);
@@ -288,7 +290,14 @@ int64_t wv_problem_workspace_bytes(const wv_problem* h) { return h ? h->p.worksp
 int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
                           int32_t P, const wv_kernel_spec* spec, int32_t max_batch,
                           int32_t x_is_device, int32_t y_is_device, wv_problem** out) {
-  if (!ctx || !X || !Y || !spec || !out || N < 1 || D < 1 || P < 1 || max_batch < 1) {
+  return wv_problem_create_multi(ctx, X, N, D, Y, P, &spec, 1, max_batch, x_is_device, y_is_device, out);
+}
+
+int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
+                                int32_t P, const wv_kernel_spec* const* spec_list, int32_t n_specs,
+                                int32_t max_batch, int32_t x_is_device, int32_t y_is_device,
+                                wv_problem** out) {
+  if (!ctx || !X || !Y || !spec_list || n_specs < 1 || !out || N < 1 || D < 1 || P < 1 || max_batch < 1) {
     set_error("wv_problem_create: bad argument");
     return WV_E_BADARG;
   }
@@ -300,29 +309,42 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   Problem& p = h->p;
   p.ctx = &ctx->c;
   p.f32 = ctx->c.dtype == 1;
-  std::string e = Spec::parse(spec, p.spec);
-  if (!e.empty()) {
-    set_error(e);
-    return WV_E_SPEC;
+  p.specs.resize(n_specs);
+  std::vector<DevSpec> hspecs(n_specs);
+  for (int si = 0; si < n_specs; ++si) {
+    if (!spec_list[si]) {
+      set_error("wv_problem_create: null spec");
+      return WV_E_BADARG;
+    }
+    std::string e = Spec::parse(spec_list[si], p.specs[si]);
+    if (!e.empty()) {
+      set_error(e);
+      return WV_E_SPEC;
+    }
+    if (p.specs[si].n_dims != D) {
+      set_error("spec.n_dims != D");
+      return WV_E_SPEC;
+    }
+    e = build_devspec(p.specs[si], hspecs[si]);
+    if (!e.empty()) {
+      set_error(e);
+      return WV_E_UNSUPPORTED;
+    }
+    p.np_stride = std::max(p.np_stride, p.specs[si].n_params());
+    p.max_feat = std::max(p.max_feat, (int)hspecs[si].n_feat);
   }
-  if (p.spec.n_dims != D) {
-    set_error("spec.n_dims != D");
-    return WV_E_SPEC;
-  }
-  e = build_devspec(p.spec, p.hspec);
-  if (!e.empty()) {
-    set_error(e);
-    return WV_E_UNSUPPORTED;
-  }
+  for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
+  p.spec = p.specs[0];
+  p.hspec = hspecs[0];
   WV_HIP_TRY(hipSetDevice(ctx->c.device));
   p.N = N;
   p.Npad = (N + NB - 1) / NB * NB;
   p.D = D;
   p.P = P;
   p.max_batch = max_batch;
-  p.out_stride = out_stride_for(p.spec.n_params());
+  p.out_stride = out_stride_for(p.np_stride);
   const int64_t Np = p.Npad, mat = Np * Np;
-  const int np = p.spec.n_params();
+  const int np = p.np_stride;
   int64_t total = 0;
   auto alloc = [&](void** ptr, int64_t bytes) -> bool {
     if (hipMalloc(ptr, (size_t)bytes) != hipSuccess) {
@@ -333,7 +355,8 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
     return true;
   };
   bool ok = alloc((void**)&p.dX, sizeof(double) * Np * D) && alloc((void**)&p.dY, sizeof(double) * Np * P) &&
-            alloc((void**)&p.dspec, sizeof(DevSpec)) &&
+            alloc((void**)&p.dspec, sizeof(DevSpec) * n_specs) &&
+            alloc((void**)&p.dslotspec, sizeof(int32_t) * max_batch) &&
             (p.f32 ? alloc((void**)&p.Kbuf32, sizeof(float) * mat * max_batch) &&
                          alloc((void**)&p.Mbuf32, sizeof(float) * mat * max_batch) &&
                          alloc((void**)&p.MTbuf32, sizeof(float) * mat * max_batch) &&
@@ -374,7 +397,8 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
   WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, Y, sizeof(double) * N, sizeof(double) * N, P,
                          y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-  WV_HIP_TRY(hipMemcpy(p.dspec, &p.hspec, sizeof(DevSpec), hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(p.dspec, hspecs.data(), sizeof(DevSpec) * n_specs, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemset(p.dslotspec, 0, sizeof(int32_t) * max_batch));
   // batch groups: independent streams, each advancing its own set of fits.  Measured on MI355X
   // (N = 2048, 1024 tasks): ONE group of 256 slots gives 3720 evaluations/s, two groups of 128 give
   // 3500 - large launches amortise the serial small kernels better than cross-stream overlap does -
@@ -395,6 +419,8 @@ int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, co
     WV_HIP_TRY(hipHostMalloc((void**)&g.h_col, sizeof(int32_t) * g.nslots));
     WV_HIP_TRY(hipHostMalloc((void**)&g.h_out, sizeof(double) * p.out_stride * g.nslots));
     WV_HIP_TRY(hipHostMalloc((void**)&g.h_status, sizeof(int32_t) * g.nslots));
+    WV_HIP_TRY(hipHostMalloc((void**)&g.h_spec, sizeof(int32_t) * g.nslots));
+    std::memset(g.h_spec, 0, sizeof(int32_t) * g.nslots);
   }
   *out = h.release();
   return WV_OK;
@@ -415,6 +441,10 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.specs.size() != 1) {
+    set_error("wv_gram: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   Group& g = p.groups[0];
   const int np = p.spec.n_params();
@@ -482,6 +512,10 @@ int32_t wv_lml(wv_problem* h, const int32_t* col_idx, int32_t B, const double* t
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.specs.size() != 1) {
+    set_error("wv_lml: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, B);
   if (rc != WV_OK) return rc;
@@ -505,6 +539,10 @@ int32_t wv_value_grad(wv_problem* h, const int32_t* col_idx, int32_t B, const do
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.specs.size() != 1) {
+    set_error("wv_value_grad: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, B);
   if (rc != WV_OK) return rc;
@@ -516,7 +554,7 @@ int32_t wv_value_grad(wv_problem* h, const int32_t* col_idx, int32_t B, const do
   rc = eval_batch(p, col_idx, B, theta.data(), true, recs, st);
   if (rc != WV_OK) return rc;
   for (int i = 0; i < B; ++i) {
-    loss_from_record(p, theta_u + (size_t)i * nt, &theta[(size_t)i * np], &recs[(size_t)i * p.out_stride],
+    loss_from_record(p.spec, theta_u + (size_t)i * nt, &theta[(size_t)i * np], &recs[(size_t)i * p.out_stride],
                      st[i], &loss_out[i], grad_out ? grad_out + (size_t)i * nt : nullptr, nullptr);
     if (status_out) status_out[i] = std::isfinite(loss_out[i]) ? 0 : 1;
   }
@@ -530,22 +568,37 @@ int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_
                           n_eval_out, status_out);
 }
 
-int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_lbfgs_opts* opts,
-                         const double* prior_scale, double* theta_u_inout, double* loss_out,
-                         double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out, int32_t* status_out) {
-  if (!h || !col_idx || !opts || !theta_u_inout || n_tasks < 1) {
-    set_error("wv_fit: bad argument");
-    return WV_E_BADARG;
-  }
+// One work queue over (column, structure) tasks: wv_fit / wv_fit_penalized (one structure) and
+// wv_fit_multi (a structure index per task) share it.  u_stride = doubles between consecutive tasks'
+// start points in theta_u_inout.
+static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* spec_idx, int32_t n_tasks,
+                        const wv_lbfgs_opts* opts, const double* prior_scale, int32_t u_stride,
+                        double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
+                        int32_t* n_eval_out, int32_t* status_out) {
   Problem& p = h->p;
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, n_tasks);
   if (rc != WV_OK) return rc;
-  const int np = p.spec.n_params(), nt = p.spec.n_trainable();
-  if (nt < 1) {
-    set_error("wv_fit: no trainable parameters");
-    return WV_E_SPEC;
+  const int np = p.np_stride;
+  int nt_max = 0;
+  for (int t = 0; t < n_tasks; ++t) {
+    const int si = spec_idx ? spec_idx[t] : 0;
+    if (si < 0 || si >= (int)p.specs.size()) {
+      set_error("wv_fit: structure index out of range");
+      return WV_E_BADARG;
+    }
+    const int nt = p.specs[si].n_trainable();
+    if (nt < 1) {
+      set_error("wv_fit: no trainable parameters");
+      return WV_E_SPEC;
+    }
+    if (nt > u_stride) {
+      set_error("wv_fit: u_stride smaller than a structure's number of trainable parameters");
+      return WV_E_BADARG;
+    }
+    nt_max = std::max(nt_max, nt);
   }
+  auto spec_of = [&](int task) -> const Spec& { return p.specs[spec_idx ? spec_idx[task] : 0]; };
   struct Slot {
     int task = -1;
     std::unique_ptr<Lbfgs> opt;
@@ -555,7 +608,7 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
   std::vector<std::vector<Slot>> slots(ng);
   std::vector<int> inflight(ng, 0);  // number of slots evaluated by the pending launch
   int next_task = 0, finished = 0;
-  std::vector<double> gu(nt), theta(np);
+  std::vector<double> gu(nt_max), theta(np);
 
   auto refill_and_launch = [&](int gi) -> int {
     Group& g = p.groups[gi];
@@ -567,15 +620,18 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
     while ((int)act.size() < g.nslots && next_task < n_tasks) {
       Slot s;
       s.task = next_task++;
-      s.opt.reset(new Lbfgs(nt, *opts, theta_u_inout + (size_t)s.task * nt));
+      s.opt.reset(new Lbfgs(spec_of(s.task).n_trainable(), *opts, theta_u_inout + (size_t)s.task * u_stride));
       act.push_back(std::move(s));
     }
     sl = std::move(act);
     inflight[gi] = (int)sl.size();
     if (sl.empty()) return WV_OK;
     for (size_t i = 0; i < sl.size(); ++i) {
-      p.spec.constrain(sl[i].opt->x(), g.h_theta + i * np);
+      const Spec& sp = spec_of(sl[i].task);
+      if (sp.n_params() < np) std::fill(g.h_theta + i * np + sp.n_params(), g.h_theta + (i + 1) * np, 0.0);
+      sp.constrain(sl[i].opt->x(), g.h_theta + i * np);
       g.h_col[i] = col_idx[sl[i].task];
+      g.h_spec[i] = spec_idx ? spec_idx[sl[i].task] : 0;
     }
     return enqueue_eval(p, g, (int)sl.size(), true);
   };
@@ -610,21 +666,22 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
       double loss, lml;
       // h_theta still holds the constrained table this evaluation used
       const double ps = prior_scale ? prior_scale[s.task] : -1.0;
-      loss_from_record(p, s.opt->x(), g.h_theta + i * np, g.h_out + i * p.out_stride, g.h_status[i], &loss,
+      const Spec& sp = spec_of(s.task);
+      loss_from_record(sp, s.opt->x(), g.h_theta + i * np, g.h_out + i * p.out_stride, g.h_status[i], &loss,
                        gu.data(), &lml, ps);
       int task = s.opt->feed(loss, gu.data());
       if (std::isfinite(loss)) s.last_lml = lml;
       if (task != WV_LB_FG) {
         const int t = s.task;
-        std::memcpy(theta_u_inout + (size_t)t * nt, s.opt->x(), sizeof(double) * nt);
+        std::memcpy(theta_u_inout + (size_t)t * u_stride, s.opt->x(), sizeof(double) * sp.n_trainable());
         if (loss_out) loss_out[t] = s.opt->f();
         if (n_iter_out) n_iter_out[t] = s.opt->n_iter();
         if (n_eval_out) n_eval_out[t] = s.opt->n_eval();
         if (status_out) status_out[t] = task;
         if (lml_out) {
           // LML at the returned point = -(loss) - log prior
-          p.spec.constrain(s.opt->x(), theta.data());
-          lml_out[t] = -s.opt->f() - p.spec.log_prior(theta.data(), nullptr, ps);
+          sp.constrain(s.opt->x(), theta.data());
+          lml_out[t] = -s.opt->f() - sp.log_prior(theta.data(), nullptr, ps);
         }
         s.task = -1;
         ++finished;
@@ -664,6 +721,33 @@ int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks,
     fprintf(stderr, "[wv_fit] %d tasks, %ld group-rounds, %ld evals (%.1f per round), wall %.3f s: wait %.3f host %.3f launch %.3f\n",
             n_tasks, n_rounds, n_evals, (double)n_evals / std::max(1L, n_rounds), now() - t_begin, t_wait, t_host, t_launch);
   return WV_OK;
+}
+
+int32_t wv_fit_penalized(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_lbfgs_opts* opts,
+                         const double* prior_scale, double* theta_u_inout, double* loss_out,
+                         double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out, int32_t* status_out) {
+  if (!h || !col_idx || !opts || !theta_u_inout || n_tasks < 1) {
+    set_error("wv_fit: bad argument");
+    return WV_E_BADARG;
+  }
+  if (h->p.specs.size() != 1) {
+    set_error("wv_fit: the problem holds several structures, use wv_fit_multi");
+    return WV_E_BADARG;
+  }
+  return fit_impl(h, col_idx, nullptr, n_tasks, opts, prior_scale, h->p.spec.n_trainable(), theta_u_inout, loss_out,
+                  lml_out, n_iter_out, n_eval_out, status_out);
+}
+
+int32_t wv_fit_multi(wv_problem* h, const int32_t* col_idx, const int32_t* spec_idx, int32_t n_tasks,
+                     const wv_lbfgs_opts* opts, const double* prior_scale, int32_t u_stride,
+                     double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
+                     int32_t* n_eval_out, int32_t* status_out) {
+  if (!h || !col_idx || !spec_idx || !opts || !theta_u_inout || n_tasks < 1 || u_stride < 1) {
+    set_error("wv_fit_multi: bad argument");
+    return WV_E_BADARG;
+  }
+  return fit_impl(h, col_idx, spec_idx, n_tasks, opts, prior_scale, u_stride, theta_u_inout, loss_out, lml_out,
+                  n_iter_out, n_eval_out, status_out);
 }
 
 // Runs the value+gradient pipeline for one task in slot 0 of group 0 and leaves alpha (dalpha),
@@ -747,6 +831,10 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.specs.size() != 1) {
+    set_error("wv_predict: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
   if (p.f32) {
     set_error("wv_predict: not implemented for float32 problems (create the problem on a float64 context)");
     return WV_E_UNSUPPORTED;
@@ -847,6 +935,10 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.specs.size() != 1) {
+    set_error("wv_whitened_means: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
   if (p.f32) {
     set_error("wv_whitened_means: not implemented for float32 problems (create the problem on a float64 context)");
     return WV_E_UNSUPPORTED;

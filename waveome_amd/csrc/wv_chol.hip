@@ -188,13 +188,15 @@ void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
 // ---------------------------------------------------------------------------------------
 // residual r = y[col] - c (zero on padded rows); also clears the slot's status word
 // ---------------------------------------------------------------------------------------
-__global__ void resid_kernel(const DevSpec* __restrict__ sp, const double* __restrict__ Y,
+__global__ void resid_kernel(const DevSpec* __restrict__ specs, const int32_t* __restrict__ slot_spec,
+                             const double* __restrict__ Y,
                              const int32_t* __restrict__ col, const double* __restrict__ theta,
                              double* __restrict__ r, int32_t* __restrict__ status, int64_t N,
                              int64_t Npad, int slot0) {
   const int b = slot0 + blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Npad) return;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const double c = sp->mean_param >= 0 ? theta[(int64_t)b * sp->n_params + sp->mean_param] : 0.0;
   r[(int64_t)b * Npad + i] = (i < N) ? Y[(int64_t)col[b] * Npad + i] - c : 0.0;
   if (i == 0) status[b] = 0;
@@ -202,7 +204,7 @@ __global__ void resid_kernel(const DevSpec* __restrict__ sp, const double* __res
 
 void launch_resid(Problem& p, hipStream_t st, int slot0, int nb) {
   dim3 grid((unsigned)((p.Npad + 255) / 256), nb);
-  hipLaunchKernelGGL(resid_kernel, grid, dim3(256), 0, st, p.dspec, p.dY, p.dcol, p.dtheta, p.dr,
+  hipLaunchKernelGGL(resid_kernel, grid, dim3(256), 0, st, p.dspec, p.dslotspec, p.dY, p.dcol, p.dtheta, p.dr,
                      p.dstatus, p.N, p.Npad, slot0);
 }
 
@@ -372,7 +374,8 @@ __device__ inline double block_sum(double v, double* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__ sp,
+__global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__ specs,
+                                                     const int32_t* __restrict__ slot_spec,
                                                      const double* __restrict__ zall,
                                                      const double* __restrict__ aall,
                                                      const double* __restrict__ logdet,
@@ -381,7 +384,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
                                                      int64_t Npad, int nblk, int nwg,
                                                      int out_stride, int slot0, int with_grad) {
   __shared__ double sh[4];
-  const int b = slot0 + blockIdx.x, tid = threadIdx.x, np = sp->n_params;
+  const int b = slot0 + blockIdx.x, tid = threadIdx.x;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+  const int np = sp->n_params;
   double q = 0.0, sa = 0.0, ld = 0.0;
   for (int64_t i = tid; i < Npad; i += 256) {
     double zz = zall[(int64_t)b * Npad + i];
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
 
 void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad) {
   p.timer.begin(st, ST_REDUCE);
-  hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dz, p.dalpha, p.dlogdet,
+  hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dslotspec, p.dz, p.dalpha, p.dlogdet,
                      p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p), p.out_stride, slot0,
                      with_grad ? 1 : 0);
   p.timer.end(st);

@@ -127,12 +127,20 @@ struct Group {
   int32_t* h_col = nullptr;    // [nslots]
   double* h_out = nullptr;     // [nslots][out_stride]
   int32_t* h_status = nullptr; // [nslots]
+  int32_t* h_spec = nullptr;   // [nslots] structure index of each slot's task (multi-structure problems)
 };
 
 struct Problem {
   Ctx* ctx = nullptr;
-  Spec spec;
+  Spec spec;      // structure 0 (the only one of a single-structure problem)
   DevSpec hspec;
+  // Multi-structure problems (wv_problem_create_multi): several kernel structures share X, Y and the
+  // workspace; every slot carries the index of its task's structure.  All device tables use the common
+  // stride np_stride = max n_params (each DevSpec's n_params field holds that stride; the unused tail of
+  // a slot's parameter row / gradient record is zero).
+  std::vector<Spec> specs;
+  int np_stride = 0, max_feat = 0;
+  int32_t* dslotspec = nullptr;  // [max_batch]
   int64_t N = 0, Npad = 0;
   int D = 0, P = 0, max_batch = 0;
   int out_stride = 0;  // doubles per slot in the result record

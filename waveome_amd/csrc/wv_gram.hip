@@ -257,7 +257,8 @@ __device__ inline void tri_decode(int t, int& ti, int& tj) {
 }
 
 template <typename R>
-__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ sp,
+__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
+                                                   const int32_t* __restrict__ slot_spec,
                                                    const double* __restrict__ X,
                                                    const double* __restrict__ theta_all,
                                                    R* __restrict__ Kall, int64_t N,
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
                                                    uint64_t term_mask, double diag_override) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const int16_t* slots = sp->fslots;
   const double* th = theta_all + (int64_t)b * sp->n_params;
   R* K = Kall + (int64_t)b * Npad * Npad;
@@ -375,7 +377,7 @@ void launch_gram_rect(Problem& p, hipStream_t st, const double* dXnew, int64_t M
                       const double* dtheta_row, double* out) {
   const int tiles_n = (int)(p.Npad / GT);
   dim3 grid((unsigned)((Mpad / GT) * tiles_n)), blk(256);
-  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
+  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);  // (prediction: structure 0)
   hipLaunchKernelGGL(gram_rect_kernel, grid, blk, sh, st, p.dspec, dXnew, p.dX, dtheta_row, out, Mrow, p.N,
                      p.Npad, p.D, tiles_n);
 }
@@ -391,7 +393,8 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // part[b][wg][p] = sum over this workgroup's tiles of  w_ij W_ij dK_ij/dtheta_p
 // (w = 1 below the diagonal, 1/2 on it, 0 above; noise_param gets 1/2 W_ii).
 template <typename R>
-__global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ sp,
+__global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ specs,
+                                                    const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ X,
                                                     const double* __restrict__ theta_all,
                                                     const R* __restrict__ Kinv_all,
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
                                                     int nwg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const int16_t* slots = sp->fslots;
   const int np = sp->n_params;
   const double* th = theta_all + (int64_t)b * np;
@@ -484,24 +488,24 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
   dim3 grid(p.ntiles(), nb), blk(256);
-  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
+  size_t sh = (size_t)2 * p.max_feat * GT * sizeof(double);
   if (p.f32)
-    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad, p.D,
+    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad, p.D,
                        slot0, 0, term_mask, diag);
   else
-    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D,
+    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D,
                        slot0, 0, term_mask, diag);
 }
 
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper) {
   dim3 grid(p.ntiles(), nb), blk(256);
-  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);
+  size_t sh = (size_t)2 * p.max_feat * GT * sizeof(double);
   p.timer.begin(st, ST_GRAM);
   if (p.f32)
-    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad,
+    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad,
                        p.D, slot0, write_upper, ~0ull, -1.0);
   else
-    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
+    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
                        p.D, slot0, write_upper, ~0ull, -1.0);
   p.timer.end(st);
   p.timer.work(ST_GRAM, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
@@ -512,13 +516,13 @@ int trace_nwg(const Problem& p) { return (p.ntiles() + TRACE_TPW - 1) / TRACE_TP
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   int nwg = trace_nwg(p);
   dim3 grid(nwg, nb), blk(256);
-  size_t sh = ((size_t)2 * p.hspec.n_feat * GT + 4 * p.hspec.n_params) * sizeof(double);
+  size_t sh = ((size_t)2 * p.max_feat * GT + 4 * p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
   if (p.f32)
-    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf32, p.dalpha,
+    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.dalpha,
                        p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
   else
-    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dX, p.dtheta, p.Kbuf, p.dalpha,
+    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.dalpha,
                        p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
   p.timer.end(st);
   p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));

@@ -94,8 +94,13 @@ class Problem:
         """X: (N, D) array, Y: (N, P) array (one column per output).  Alternatively pass raw device
         pointers (x_device_ptr -> N x D row-major, y_device_ptr -> P x N row-major) with
         shape=(N, D, P), e.g. buffers filled by an RCCL broadcast."""
-        self.ctx, self.lib, self.spec = ctx, ctx.lib, spec
-        self._cspec = spec.to_ctypes()
+        self.ctx, self.lib = ctx, ctx.lib
+        # a list of specs makes a multi-structure problem (fit_multi only): tasks of different kernel
+        # structures share the workspace and one work queue
+        self.specs = list(spec) if isinstance(spec, (list, tuple)) else [spec]
+        self.spec = spec = self.specs[0]
+        self._cspecs = [sp.to_ctypes() for sp in self.specs]
+        self._cspec = self._cspecs[0]
         self.handle = C.c_void_p()
         if x_device_ptr is not None:
             N, D, P = (int(v) for v in shape)
@@ -113,9 +118,15 @@ class Problem:
             self._X = X
             xp, yp, xd, yd = C.c_void_p(X.ctypes.data), C.c_void_p(self._Yt.ctypes.data), 0, 0
         self.N, self.D, self.P, self.max_batch = N, D, P, int(max_batch)
-        _lib.check(self.lib.wv_problem_create(ctx.handle, xp, N, D, yp, P, C.byref(self._cspec),
-                                              int(max_batch), xd, yd, C.byref(self.handle)),
-                   "wv_problem_create")
+        if len(self.specs) == 1:
+            _lib.check(self.lib.wv_problem_create(ctx.handle, xp, N, D, yp, P, C.byref(self._cspec),
+                                                  int(max_batch), xd, yd, C.byref(self.handle)),
+                       "wv_problem_create")
+        else:
+            arr = (C.POINTER(_lib.KernelSpec) * len(self.specs))(*[C.pointer(cs) for cs in self._cspecs])
+            _lib.check(self.lib.wv_problem_create_multi(ctx.handle, xp, N, D, yp, P, arr, len(self.specs),
+                                                        int(max_batch), xd, yd, C.byref(self.handle)),
+                       "wv_problem_create_multi")
         self.n_params = spec.n_params
         self.n_trainable = spec.n_trainable
 
@@ -176,6 +187,31 @@ class Problem:
                                              _lib.as_dp(ps) if ps is not None else None, _lib.as_dp(U),
                                              _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit),
                                              _lib.as_ip(nfev), _lib.as_ip(st)), "wv_fit_penalized")
+        return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
+
+    def fit_multi(self, cols, spec_idx, U0, opts=None, prior_scale=None):
+        """Fit tasks that differ in kernel structure as well as in column: task t uses self.specs[spec_idx[t]].
+        U0: (T, width) start points, width >= the largest n_trainable (a task uses the first n_trainable of
+        its row).  Returns the same dict as fit(); rows of "u" are padded with NaN past n_trainable."""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        sidx = np.ascontiguousarray(spec_idx, dtype=np.int32)
+        T = len(cols)
+        width = max(sp.n_trainable for sp in self.specs)
+        U = np.array(U0, dtype=np.float64, order="C", copy=True)
+        if U.ndim != 2 or U.shape[0] != T or U.shape[1] < width or len(sidx) != T:
+            raise ValueError(f"U0 must be ({T}, >= {width}) and spec_idx ({T},)")
+        opts = opts or lbfgs_opts()
+        loss, lml = np.empty(T), np.empty(T)
+        nit, nfev, st = (np.empty(T, dtype=np.int32) for _ in range(3))
+        ps = None
+        if prior_scale is not None:
+            ps = np.ascontiguousarray(np.broadcast_to(prior_scale, (T,)), dtype=np.float64)
+        _lib.check(self.lib.wv_fit_multi(self.handle, _lib.as_ip(cols), _lib.as_ip(sidx), T, C.byref(opts),
+                                         _lib.as_dp(ps) if ps is not None else None, U.shape[1], _lib.as_dp(U),
+                                         _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit), _lib.as_ip(nfev),
+                                         _lib.as_ip(st)), "wv_fit_multi")
+        nts = np.array([self.specs[i].n_trainable for i in sidx])
+        U[np.arange(U.shape[1])[None, :] >= nts[:, None]] = np.nan
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
 
     def predict(self, col, theta, include_noise=True, Xnew=None):

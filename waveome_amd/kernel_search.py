@@ -297,12 +297,12 @@ def structure_signature(spec: ModelSpec) -> str:
 
 
 class GpuScorer:
-    """Scores (column, kernel) candidates: one Problem per distinct structure, all its columns in one
-    batched fit.  This is `kernel_test` (model_search.py:2239-2334) for penalization_factor = 0,
+    """Scores (column, kernel) candidates: all candidates of a step, whatever their structure, in one batched
+    work queue on the GPU.  This is `kernel_test` (model_search.py:2239-2334) for penalization_factor = 0,
     `num_restart <= 1`: L-BFGS-B from the default values, `bic = round(2k - 2 log_posterior, 2)` with k =
     number of trainable Parameter objects (q_mu and q_sqrt of the reference's SVGP included, hence + 2)."""
 
-    def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None):
+    def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None, mode=None):
         from .engine import lbfgs_opts
         from .model_classes import default_context
 
@@ -310,10 +310,13 @@ class GpuScorer:
         self.Y = np.ascontiguousarray(Y, dtype=np.float64)
         self.ctx = context or default_context()
         self.max_batch = max_batch
-        # structure batches in flight: each is its own Problem (own HIP streams) driven from its own host
-        # thread - the C-ABI calls release the GIL, hold no global state and set the device themselves.
-        # A search step is many small batches (a handful of columns per structure), each launch-latency
-        # bound on its own, so they are overlapped on the GPU instead of queued behind one another.
+        # A search step is many structures with a handful of columns each.  mode "multi" (default): one
+        # multi-structure problem per step (wv_problem_create_multi / wv_fit_multi) - every launch mixes
+        # structures, the batch stays full.  mode "threads": one Problem per structure, `workers` of them in
+        # flight from host threads (kept for comparison: 3x faster than one at a time, 2.5x slower than "multi").
+        self.mode = mode or os.environ.get("WV_SEARCH_MODE", "multi")
+        if self.mode not in ("multi", "threads"):
+            raise ValueError("mode must be 'multi' or 'threads'")
         self.workers = int(workers if workers is not None else os.environ.get("WV_SEARCH_WORKERS", 16))
         self.opts = lbfgs_opts(maxiter=num_opt_iter)
         self.n_fits = 0
@@ -347,6 +350,27 @@ class GpuScorer:
             by_sig: Dict[str, List[int]] = {}
             for row, i in enumerate(mine):
                 by_sig.setdefault(sigs[i], []).append(row)
+            if self.mode == "multi":
+                # ONE multi-structure problem and one work queue for the whole shard: every launch mixes
+                # structures, so the batch stays full however few columns ask for any one structure
+                sig_list = list(by_sig)
+                sp_list = [specs[mine[by_sig[sg][0]]] for sg in sig_list]
+                sidx = np.empty(len(mine), dtype=np.int32)
+                for k, sg in enumerate(sig_list):
+                    sidx[by_sig[sg]] = k
+                cols = np.array([tasks[i][0] for i in mine], dtype=np.int32)
+                U0 = np.zeros((len(mine), width))
+                for k, sp in enumerate(sp_list):
+                    U0[sidx == k, :sp.n_trainable] = sp.unconstrain()
+                mb = self.max_batch or min(len(mine), _default_batch(N))
+                prob = Problem(self.ctx, self.X, self.Y, sp_list, max_batch=max(1, mb))
+                try:
+                    res = prob.fit_multi(cols, sidx, U0, self.opts)
+                finally:
+                    prob.close()
+                rec[:, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
+                rec[:, 5:5 + width] = res["u"][:, :width]
+                return rec
 
             def fit_structure(rows):
                 sp = specs[mine[rows[0]]]
@@ -360,7 +384,8 @@ class GpuScorer:
                 rec[rows, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
                 rec[rows, 5:5 + sp.n_trainable] = res["u"]
 
-            # heaviest first; device memory in flight is bounded by workers x one Problem
+            # mode "threads": one Problem per structure, several in flight from host threads (each has its own
+            # HIP streams; the C-ABI calls release the GIL).  Heaviest first; memory bounded by workers x Problem
             work = sorted(by_sig.values(), key=lambda rows: -len(rows) * specs[mine[rows[0]]].n_trainable)
             per_problem = max(1, min(max(len(r) for r in work), _default_batch(N))) * 2 * (N + 64) ** 2 * 8
             nw = max(1, min(self.workers, len(work), (48 << 30) // per_problem))
