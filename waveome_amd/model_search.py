@@ -238,7 +238,7 @@ class GPSearch:
 
         kernels: dict name -> kernel (or a list; names default to the printed structure).
         Tasks are sharded over ranks when torch.distributed is initialised (cost ~ parameters per
-        structure), one Problem per structure per rank.  Returns a DataFrame indexed by
+        structure); a rank's tasks run as one multi-structure work queue (`wv_fit_multi`).  Returns a DataFrame indexed by
         (output, structure) with loss, lml, bic, nit, nfev, status; `self.sweep_models[(output, name)]`
         holds the fitted PSVGP objects when keep_models."""
         from .utilities import print_kernel_names
@@ -275,17 +275,23 @@ class GPSearch:
         costs = np.array([specs[s_].n_trainable for s_ in task_s], dtype=np.float64)
 
         def fit_shard(ids):
+            # one multi-structure problem and one work queue for the whole shard (wv_fit_multi)
             out = np.full((len(ids), 5 + width), np.nan)
-            for s_ in np.unique(task_s[ids]):
-                sel = np.nonzero(task_s[ids] == s_)[0]
-                sp = specs[s_]
-                mb = max_batch or min(len(sel), _default_batch(N))
-                prob = Problem(ctx, Xn, Yn, sp, max_batch=max(1, mb))
-                local = ids[sel] - s_ * P * n_starts  # row inside this structure's start block
-                res = prob.fit(task_p[ids[sel]].astype(np.int32), starts[s_][local], opts)
+            used = np.unique(task_s[ids])
+            local_of = {int(s_): k for k, s_ in enumerate(used)}
+            sidx = np.array([local_of[int(s_)] for s_ in task_s[ids]], dtype=np.int32)
+            U0 = np.zeros((len(ids), width))
+            for row, t in enumerate(ids):
+                s_ = task_s[t]
+                U0[row, :specs[s_].n_trainable] = starts[s_][t - s_ * P * n_starts]
+            mb = max_batch or min(len(ids), _default_batch(N))
+            prob = Problem(ctx, Xn, Yn, [specs[s_] for s_ in used], max_batch=max(1, mb))
+            try:
+                res = prob.fit_multi(task_p[ids].astype(np.int32), sidx, U0, opts)
+            finally:
                 prob.close()
-                out[sel, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
-                out[sel, 5:5 + sp.n_trainable] = res["u"]
+            out[:, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
+            out[:, 5:5 + width] = res["u"][:, :width]
             return out
 
         rank, world = parallel.dist_info()
