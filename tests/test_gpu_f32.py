@@ -124,7 +124,9 @@ def test_f32_fit_reaches_the_float64_optimum(ctx32, ctx64):
     np.testing.assert_allclose(r32["loss"], r64["loss"], rtol=1e-4)
     th32 = np.stack([spec.constrain(u) for u in r32["u"]])
     th64 = np.stack([spec.constrain(u) for u in r64["u"]])
-    np.testing.assert_allclose(th32, th64, rtol=5e-2, atol=1e-2)  # flat directions (mean, tiny variances)
+    # the constant mean is a nearly flat direction next to a long-lengthscale SE term: loose on it alone
+    np.testing.assert_allclose(th32[:, :-1], th64[:, :-1], rtol=5e-2, atol=1e-2)
+    np.testing.assert_allclose(th32[:, -1], th64[:, -1], atol=0.1)
 
 
 def test_f32_unsupported_entries_say_so(ctx32):
@@ -189,3 +191,44 @@ def test_config_c5_float32_n16384(ctx32, ctx64):
     assert abs(f32[0] - f64[0]) <= 1e-4 * abs(f64[0])
     assert abs(-l32[0] - f64[0]) <= 1e-4 * abs(f64[0])
     assert np.max(np.abs(g32 - g64)) <= 2e-2 * np.max(np.abs(g64))
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 65, 129])
+def test_f32_ragged_and_tiny_sizes(ctx32, ctx64, N):
+    from waveome_amd.engine import Problem
+
+    X, Y = _data(11, N)
+    spec = ModelSpec(K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])]), 3,
+                     K.GaussianLikelihood(), K.ConstantMean())
+    u = spec.unconstrain()[None, :]
+    cols = np.zeros(1, dtype=np.int32)
+    p64 = Problem(ctx64, X, Y, spec, max_batch=1)
+    f64, g64, _ = p64.value_grad(cols, u)
+    p64.close()
+    p32 = Problem(ctx32, X, Y, spec, max_batch=1)
+    f32, g32, st = p32.value_grad(cols, u)
+    p32.close()
+    assert st[0] == 0
+    assert abs(f32[0] - f64[0]) <= 2e-5 * max(1.0, abs(f64[0]))
+    assert np.max(np.abs(g32 - g64)) <= 2e-3 * max(1.0, np.max(np.abs(g64)))
+
+
+def test_f32_multi_structure_fit(ctx32, ctx64):
+    """The multi-structure work queue on a float32 context: same optima as on the float64 one."""
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(13, 300)
+    specs = [ModelSpec(k, 3, K.GaussianLikelihood(), K.ConstantMean()) for k in
+             (K.SquaredExponential(active_dims=[0]), K.Sum([K.Matern32(active_dims=[0]), K.Lin(active_dims=[1])]))]
+    cols = np.array([0, 1, 1, 0], dtype=np.int32)
+    sidx = np.array([0, 1, 0, 1], dtype=np.int32)
+    width = max(sp.n_trainable for sp in specs)
+    U0 = np.zeros((4, width))
+    for t, si in enumerate(sidx):
+        U0[t, :specs[si].n_trainable] = specs[si].unconstrain()
+    out = {}
+    for name, c in (("f32", ctx32), ("f64", ctx64)):
+        prob = Problem(c, X, Y, specs, max_batch=4)
+        out[name] = prob.fit_multi(cols, sidx, U0, lbfgs_opts())
+        prob.close()
+    np.testing.assert_allclose(out["f32"]["loss"], out["f64"]["loss"], rtol=1e-4)

@@ -145,16 +145,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(R* __restrict__ Kall, R
     }
   }
   // ---- inverse of the lower-triangular block by recursive doubling ----
-  if (tid < 64) {  // level 0: four 16x16 diagonal blocks, one thread per column
-    const int blk = tid >> 4, c = tid & 15, o = blk * 16;
+  if (tid < 64) {  // level 0: sixteen 4x4 diagonal blocks, one thread per column (a short dependent chain)
+    const int blk = tid >> 2, c = tid & 3, o = blk * 4;
     X[(o + c) * DS + o + c] = R(1) / L[(o + c) * DS + o + c];
-    for (int i = c + 1; i < 16; ++i) {
+    for (int i = c + 1; i < 4; ++i) {
       R s = 0;
       for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
       X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
     }
   }
   __syncthreads();
+  inv_level<4>(L, X, T, tid);
+  inv_level<8>(L, X, T, tid);
   inv_level<16>(L, X, T, tid);
   inv_level<32>(L, X, T, tid);
 #pragma unroll
