@@ -40,7 +40,7 @@ import numpy as np
 from . import kernels as K
 from . import parallel
 from .spec import ModelSpec
-from .utilities import calc_bic, check_if_model_exists
+from .utilities import calc_bic, check_if_model_exists, restart_points
 
 
 # ---------------------------------------------------------------------------------------------
@@ -302,7 +302,8 @@ class GpuScorer:
     `num_restart <= 1`: L-BFGS-B from the default values, `bic = round(2k - 2 log_posterior, 2)` with k =
     number of trainable Parameter objects (q_mu and q_sqrt of the reference's SVGP included, hence + 2)."""
 
-    def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None, mode=None):
+    def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None, mode=None,
+                 num_restart=1, random_seed=None):
         from .engine import lbfgs_opts
         from .model_classes import default_context
 
@@ -310,6 +311,7 @@ class GpuScorer:
         self.Y = np.ascontiguousarray(Y, dtype=np.float64)
         self.ctx = context or default_context()
         self.max_batch = max_batch
+        self.num_restart, self.random_seed = max(1, int(num_restart)), random_seed
         # A search step is many structures with a handful of columns each.  mode "multi" (default): one
         # multi-structure problem per step (wv_problem_create_multi / wv_fit_multi) - every launch mixes
         # structures, the batch stays full.  mode "threads": one Problem per structure, `workers` of them in
@@ -359,18 +361,32 @@ class GpuScorer:
                 for k, sg in enumerate(sig_list):
                     sidx[by_sig[sg]] = k
                 cols = np.array([tasks[i][0] for i in mine], dtype=np.int32)
-                U0 = np.zeros((len(mine), width))
+                R = self.num_restart  # R > 1: seeded random starts, the best LML is kept (kernel_test :2283-2288)
+                rep = np.repeat(np.arange(len(mine)), R)
+                cols_r, sidx_r = cols[rep], sidx[rep]
+                U0 = np.zeros((len(rep), width))
                 for k, sp in enumerate(sp_list):
-                    U0[sidx == k, :sp.n_trainable] = sp.unconstrain()
-                mb = self.max_batch or min(len(mine), _default_batch(N))
+                    rows = np.nonzero(sidx_r == k)[0]
+                    if R == 1:
+                        U0[rows, :sp.n_trainable] = sp.unconstrain()
+                    else:
+                        pts = restart_points(sp.n_trainable, R, random_seed=self.random_seed)
+                        U0[rows, :sp.n_trainable] = np.tile(pts, (len(rows) // R, 1))
+                mb = self.max_batch or min(len(rep), _default_batch(N))
                 prob = Problem(self.ctx, self.X, self.Y, sp_list, max_batch=max(1, mb))
                 try:
-                    res = prob.fit_multi(cols, sidx, U0, self.opts)
+                    res = prob.fit_multi(cols_r, sidx_r, U0, self.opts)
                 finally:
                     prob.close()
-                rec[:, :5] = np.column_stack([res["loss"], res["lml"], res["nit"], res["nfev"], res["status"]])
-                rec[:, 5:5 + width] = res["u"][:, :width]
+                lml = np.where(np.isfinite(res["lml"]), res["lml"], -np.inf).reshape(len(mine), R)
+                best = np.arange(len(mine)) * R + np.argmax(lml, axis=1)
+                rec[:, :5] = np.column_stack([res["loss"][best], res["lml"][best], res["nit"][best],
+                                              res["nfev"][best], res["status"][best]])
+                rec[:, 5:5 + width] = res["u"][best, :width]
                 return rec
+
+            if self.num_restart > 1:
+                raise NotImplementedError("random restarts are implemented in mode 'multi' only")
 
             def fit_structure(rows):
                 sp = specs[mine[rows[0]]]

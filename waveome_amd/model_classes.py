@@ -19,7 +19,7 @@ from . import kernels as K
 from .engine import Context, Problem, lbfgs_opts
 from .spec import ModelSpec
 from .spec import _expand
-from .utilities import (_gaussian_logdensity, calc_bic, calc_feature_importance_components, calc_rsquare, find_variance_components,
+from .utilities import (_gaussian_logdensity, restart_points, calc_bic, calc_feature_importance_components, calc_rsquare, find_variance_components,
                         print_kernel_names, search_through_kernel_list_)
 
 _default_ctx: Optional[Context] = None
@@ -194,16 +194,7 @@ class PSVGP:
         return twin
 
     def _restart_points(self, num_restart, loc=0.0, scale=1.0, random_seed=None):
-        """Start points of `random_restart_optimize` (:472-524): restart i draws every unconstrained
-        value ~ N(loc, scale) under `np.random.seed(seed)` with seed = i for random_seed None, else
-        random_seed + i + 1 (:498-503, 181-234).  (The reference's draws also feed q_mu / q_sqrt, which this
-        exact-GP path does not have, so the numbers differ from the reference's for the same seed.)"""
-        nt = self._spec().n_trainable
-        pts = np.empty((num_restart, nt))
-        for i in range(num_restart):
-            np.random.seed(i if random_seed is None else random_seed + i + 1)
-            pts[i] = np.random.normal(loc=loc, scale=scale, size=nt)
-        return pts
+        return restart_points(self._spec().n_trainable, num_restart, loc, scale, random_seed)
 
     def random_restart_optimize(self, data=None, num_restart=5, randomize_kwargs={}, optimize_kwargs={}):
         """`num_restart` randomised fits in one batched call; keeps the one with the highest

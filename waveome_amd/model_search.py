@@ -151,10 +151,11 @@ class GPSearch:
         spec = template._spec()
         u0 = spec.unconstrain()
         n_starts = max(1, int(num_restart))
-        rng = np.random.RandomState(random_seed)
         starts = np.tile(u0, (P * n_starts, 1))
-        if num_restart > 0:  # model_classes.py:181-234: unconstrained values ~ N(0, 1)
-            starts = rng.normal(loc=0.0, scale=1.0, size=starts.shape)
+        if num_restart > 0:  # the same seeded N(0, 1) points for every output (model_classes.py:181-234, 498-503)
+            from .utilities import restart_points
+
+            starts = np.tile(restart_points(len(u0), n_starts, random_seed=random_seed), (P, 1))
         cols = np.repeat(np.arange(P, dtype=np.int32), n_starts)
 
         print(f"Building {len(self.out_names)} models...")
@@ -253,8 +254,9 @@ class GPSearch:
         N, P, S = Xn.shape[0], Yn.shape[1], len(names)
         ctx = context or default_context()
         opts = lbfgs_opts(maxiter=num_opt_iter)
+        from .utilities import restart_points
+
         n_starts = max(1, int(num_restart))
-        rng = np.random.RandomState(random_seed)
         templates, specs = [], []
         for nm in names:
             t = PSVGP(Xn, Yn[:, :1], mean_function=mean_function, kernel=kernels[nm],
@@ -270,7 +272,7 @@ class GPSearch:
             u0 = sp.unconstrain()
             blk = np.tile(u0, (P * n_starts, 1))
             if num_restart > 0:
-                blk = rng.normal(size=blk.shape)
+                blk = np.tile(restart_points(len(u0), n_starts, random_seed=random_seed), (P, 1))
             starts.append(blk)
         costs = np.array([specs[s_].n_trainable for s_ in task_s], dtype=np.float64)
 
@@ -328,8 +330,9 @@ class GPSearch:
         Matern12, Lin, Periodic(SquaredExponential).
 
         The candidates of all output columns at one search step are pooled and fitted in batched GPU
-        calls (waveome_amd/kernel_search.py); `num_jobs` is accepted and ignored, `num_restart > 1`
-        (random restarts inside `kernel_test`) is not implemented.  `scorer` replaces the GPU scorer
+        calls (waveome_amd/kernel_search.py); `num_jobs` is accepted and ignored.  `num_restart > 1`: every
+        candidate is fitted from that many seeded random start points and the fit with the best
+        `maximum_log_likelihood_objective` is scored (`kernel_test` -> `random_restart_optimize`, :2283-2288).  `scorer` replaces the GPU scorer
         (test seam: tests/ drive the search logic with the CPU oracle).  Sets `self.models[out]` (the
         best model, fitted), `self.search_info[out]` = {"models", "edges", "best_model", "var_exp"}."""
         from . import kernel_search as ks
@@ -339,8 +342,6 @@ class GPSearch:
         self.verbose = verbose
         if self.likelihood != "gaussian":
             raise NotImplementedError("only outcome_likelihood='gaussian' is implemented on the GPU path")
-        if num_restart > 1:
-            raise NotImplementedError("run_search with num_restart > 1 (random restarts per candidate)")
         if kernels is None:
             kernels = [K.SquaredExponential(), K.Matern12(), K.Lin(), K.Periodic(K.SquaredExponential())]
         if random_seed is not None:
@@ -351,7 +352,8 @@ class GPSearch:
         print(f"Building {len(self.out_names)} models...")
         start_time = time.time()
         if scorer is None:
-            scorer = ks.GpuScorer(Xn, Yn, context=context, max_batch=max_batch)
+            scorer = ks.GpuScorer(Xn, Yn, context=context, max_batch=max_batch, num_restart=num_restart,
+                                  random_seed=random_seed)
         out = ks.run_searches(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
                               max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
                               early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)

@@ -26,6 +26,19 @@ def get_precision():
     return _precision
 
 
+def restart_points(n_trainable: int, num_restart: int, loc: float = 0.0, scale: float = 1.0, random_seed=None):
+    """Start points of `random_restart_optimize` (waveome/model_classes.py:472-524): restart i draws every
+    unconstrained value ~ N(loc, scale) under `np.random.seed(seed)`, seed = i when random_seed is None, else
+    random_seed + i + 1 (:498-503, 181-234).  Every model of a run gets the same points, as in the reference.
+    (The reference's draws also feed q_mu / q_sqrt, which the exact-GP path does not have, so the numbers differ
+    from the reference's for the same seed.)"""
+    pts = np.empty((num_restart, n_trainable))
+    for i in range(num_restart):
+        np.random.seed(i if random_seed is None else random_seed + i + 1)
+        pts[i] = np.random.normal(loc=loc, scale=scale, size=n_trainable)
+    return pts
+
+
 def calc_bic(loglik: float, n: int, k: int):
     """2k - 2 loglik (the reference's 'BIC' does not use log n, waveome/utilities.py:94-95)."""
     return 2 * k - 2 * loglik
