@@ -278,3 +278,33 @@ def test_pruning_rules_and_bic():
     PSVGP.cut_kernel_components(m)
     assert m.kernel.name == "constant"  # model_classes.py:1063
     assert calc_bic(loglik=-10.0, n=100, k=3) == 26.0
+
+
+def test_restart_points_are_seeded_like_the_reference():
+    """restart i: np.random.seed(i) without a seed, seed + i + 1 with one (model_classes.py:498-503)."""
+    from waveome_amd.utilities import restart_points
+
+    a = restart_points(5, 3, random_seed=7)
+    b = restart_points(5, 3, random_seed=7)
+    np.testing.assert_array_equal(a, b)
+    np.random.seed(9)  # 7 + 1 + 1
+    np.testing.assert_array_equal(a[1], np.random.normal(size=5))
+    c = restart_points(4, 2)
+    np.random.seed(1)
+    np.testing.assert_array_equal(c[1], np.random.normal(size=4))
+    d = restart_points(4, 1, loc=2.0, scale=0.0)
+    np.testing.assert_array_equal(d, np.full((1, 4), 2.0))
+
+
+def test_precision_switch_validates_its_argument():
+    from waveome_amd import utilities as U
+    from waveome_amd.engine import Context
+
+    assert U.get_precision() == "float64"
+    with pytest.raises(ValueError):
+        U.set_precision("float16")
+    with pytest.raises(ValueError):
+        Context(0, dtype="bfloat16")
+    U.set_precision("float32")
+    assert U.get_precision() == "float32"
+    U.set_precision("float64")
