@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tasks", type=int, default=1024, help="fits per GPU per step")
-    ap.add_argument("--batch", type=int, default=256, help="fits in flight per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="fits in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed per-stage step")
     args = ap.parse_args()
