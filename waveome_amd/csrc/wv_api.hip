@@ -141,13 +141,17 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
   launch_resid(p, st, g.slot0, nb);
   launch_gram(p, st, g.slot0, nb, 0);
   static const bool old_sched = std::getenv("WV_SCHED_OLD") != nullptr;
+  static const bool full_value = std::getenv("WV_VALUE_FULL") != nullptr;  // value-only through factor + inverse
   if (old_sched) {
     cholesky(p, st, g.slot0, nb);
     trtri(p, st, g.slot0, nb);
-  } else {
+    launch_solve(p, st, g.slot0, nb, with_grad);
+  } else if (with_grad || full_value) {
     factor_inverse(p, st, g.slot0, nb);
+    launch_solve(p, st, g.slot0, nb, with_grad);
+  } else {
+    factor_value_only(p, st, g.slot0, nb);  // z comes out of the factorisation itself
   }
-  launch_solve(p, st, g.slot0, nb, with_grad);
   if (with_grad) {
     lauum(p, st, g.slot0, nb);
     launch_trace(p, st, g.slot0, nb);

@@ -324,6 +324,51 @@ __global__ void alpha_reduce_kernel(const double* __restrict__ part, double* __r
   aall[(int64_t)b * Npad + j] = s;
 }
 
+// ---- value-only path: forward substitution fused into the factorisation (see factor_value_only) ----
+// z[off + i] = sum_{j <= i} M[off + i][off + j] r[off + j],  i < len: the diagonal block [off, off + len) of
+// the lower-triangular M applied to the matching piece of r.  One wave per row, 16 rows per workgroup.
+template <typename R>
+__global__ __launch_bounds__(256) void trmv_sub_kernel(const R* __restrict__ Mall, const double* __restrict__ rall,
+                                                       double* __restrict__ zall, int64_t Npad, int64_t off,
+                                                       int64_t len, int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const R* M = Mall + (int64_t)b * Npad * Npad + off * Npad + off;
+  const double* r = rall + (int64_t)b * Npad + off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t i = (int64_t)blockIdx.x * 16 + wave * 4 + rr;
+    if (i >= len) return;
+    const R* row = M + i * Npad;
+    double s = 0.0;
+    for (int64_t j = lane; j <= i; j += 64) s += (double)row[j] * r[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) zall[(int64_t)b * Npad + off + i] = s;
+  }
+}
+
+// r[roff + m] -= sum_{k < h1} St[k][m] z[zoff + k],  m < h2: the Schur-complement update of the right-hand
+// side with S = L21 held transposed (St is h1 x h2, leading dimension h2, per-slot stride sS).
+// Workgroup = 64 columns m; wave w takes rows k = w, w + 4, ...
+template <typename R>
+__global__ __launch_bounds__(256) void gemv_st_kernel(const R* __restrict__ Sall, int64_t sS, int64_t h1, int64_t h2,
+                                                      const double* __restrict__ zall, double* __restrict__ rall,
+                                                      int64_t Npad, int64_t zoff, int64_t roff, int slot0) {
+  __shared__ double red[4][64];
+  const int b = slot0 + blockIdx.y;
+  const R* S = Sall + (int64_t)b * sS;
+  const double* z = zall + (int64_t)b * Npad + zoff;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (m < h2)
+#pragma unroll 4
+    for (int64_t k = wave; k < h1; k += 4) s += (double)S[k * h2 + m] * z[k];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && m < h2) rall[(int64_t)b * Npad + roff + m] -= red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
 // generic lower-triangular products on any N x N buffer: out = T in (trans = false) or T' in
 void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* in, double* out, int slot0,
                  int nb, bool trans) {
@@ -596,6 +641,74 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     p.timer.work(ST_TRTRI_B, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// factor_value_only: log|K_y| and z = L^-1 r WITHOUT the inverse of the whole matrix (value-only evaluations:
+// wv_lml).  Node (o, n), n = h1 + h2:
+//   fi_node(o, h1)                full factor + inverse of the left block (its M11 makes the TRSM a GEMM)
+//   z1  = M11 r1                  forward substitution on the left block
+//   S   = A21 M11'                (as S')
+//   r2 -= S z1                    right-hand side of the Schur complement
+//   A22 -= S S'
+//   node(o + h1, h2)              value-only recursion on the Schur complement
+// T(n) = n^3/3 + T(n/2)  ->  0.38 N^3 instead of the 0.67 N^3 of factor + inverse; z lands in p.dz, r is consumed.
+// ---------------------------------------------------------------------------------------
+template <typename R>
+static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
+  const int64_t Np = p.Npad, mat = Np * Np;
+  const MatBufs<R> mb = mat_bufs<R>(p);
+  if (n == NB) {
+    launch_potrf_diag(p, st, slot0, nb, (int)o);
+    p.timer.begin(st, ST_SOLVE);
+    hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(NB / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o,
+                       (int64_t)NB, slot0);
+    p.timer.end(st);
+    return;
+  }
+  const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
+  R* K0 = mb.K + (int64_t)slot0 * mat;
+  R* MT0 = mb.MT + (int64_t)slot0 * mat;
+  R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();
+  const int64_t sS = p.pbuf_elems();
+  fi_node<R>(p, st, slot0, nb, o, h1);
+  p.timer.begin(st, ST_SOLVE);
+  hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(h1 / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o, h1,
+                     slot0);
+  p.timer.end(st);
+  {  // S = A21 * M11'   written transposed (same product as in fi_node)
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
+    a.A = K0 + (o + h1) * Np + o;
+    a.B = MT0 + o * Np + o;
+    a.C = nullptr;
+    a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
+    a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
+    p.timer.begin(st, ST_CHOL_TRSM);
+    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
+  }
+  p.timer.begin(st, ST_SOLVE);
+  hipLaunchKernelGGL(gemv_st_kernel<R>, dim3((unsigned)((h2 + 63) / 64), nb), dim3(256), 0, st, mb.P, sS, h1, h2, p.dz,
+                     p.dr, Np, o, o + h1, slot0);
+  p.timer.end(st);
+  {  // A22 -= S S'
+    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
+    a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h2;
+    a.C = K0 + (o + h1) * Np + (o + h1);
+    a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
+    a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
+    p.timer.begin(st, ST_CHOL_TRAIL);
+    launch_gemm(st, a, false, false, h2 > 64 ? 128 : 64);
+    p.timer.end(st);
+    p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
+  }
+  fv_node<R>(p, st, slot0, nb, o + h1, h2);
+}
+
+void factor_value_only(Problem& p, hipStream_t st, int slot0, int nb) {
+  if (p.f32) fv_node<float>(p, st, slot0, nb, 0, p.Npad);
+  else fv_node<double>(p, st, slot0, nb, 0, p.Npad);
 }
 
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb) {

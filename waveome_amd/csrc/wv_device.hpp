@@ -189,6 +189,7 @@ void cholesky(Problem& p, hipStream_t st, int slot0, int nb);
 void trtri(Problem& p, hipStream_t st, int slot0, int nb);
 void lauum(Problem& p, hipStream_t st, int slot0, int nb);
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb);  // recursive potrf + trtri
+void factor_value_only(Problem& p, hipStream_t st, int slot0, int nb);  // log-det and z = L^-1 r only
 
 // the N x N work matrices of a problem in their storage type
 template <typename T> struct MatBufs { T *K, *M, *MT, *P; };
