@@ -328,3 +328,44 @@ def test_run_search_with_random_restarts_never_scores_worse_lml():
             total += 1
             better += runs[0][f][n] >= m["fit"]["lml"] - 1e-6 * abs(m["fit"]["lml"]) - 1e-3
     assert better >= 0.8 * total  # random starts mostly find the default start's optimum or a better one
+
+
+def _name_of(kern):
+    if kern.name == "sum":
+        return "+".join(_name_of(k) for k in kern.kernels)
+    if kern.name == "product":
+        return "*".join(_name_of(k) for k in kern.kernels)
+    return ks.kernel_info(kern)
+
+
+def test_deep_search_keeps_names_structures_and_lineage_consistent():
+    """Default kernel list, depth 3, scored by the CPU oracle on a tiny data set: every recorded model's name
+    spells its kernel exactly, no structure is fitted twice under two spellings, every parent exists, products
+    stay two-way, and the reported best model has the lowest (bic, depth, name) triple."""
+    from waveome_amd.model_search import GPSearch
+
+    X, Y = search_data(n=24, seed=5)
+    gps = GPSearch(X, Y[["smooth_t"]], categorical_vars=["grp"])
+    Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+    scorer = OracleScorer(Xn, Yn)
+    res = ks.run_searches([0], 3, default_kernels(), scorer, cat_vars=[2], max_depth=3, keep_only_best=False)[0]
+    models = res["models"]
+    assert len(models) > 40 and scorer.n_fits >= len(models)
+    canon = set()
+    for name, m in models.items():
+        assert _name_of(m["kernel"]) == name
+        assert all(part.count("*") <= 1 for part in name.split("+"))
+        key = frozenset("".join(sorted(part)) for part in name.split("+"))
+        assert key not in canon, f"{name} duplicates an earlier structure"
+        canon.add(key)
+        assert m["parent"] == "None" or m["parent"] in models
+        assert 1 <= m["depth"] <= 3 and np.isfinite(m["bic"])
+        if "*" in name:  # the factor that joined a product has its variance frozen at 1 (model_search.py:2469-2472)
+            for comp in (m["kernel"].kernels if m["kernel"].name == "sum" else [m["kernel"]]):
+                if comp.name == "product":
+                    frozen = [f for f in comp.kernels
+                              if not (f.base_kernel.variance if f.name == "periodic" else f.variance).trainable]
+                    assert len(frozen) >= 1
+    assert res["best_model"] == min((m["bic"], m["depth"], n) for n, m in models.items())[2]
+    for parent, child in res["edges"]:
+        assert parent in models
