@@ -232,3 +232,29 @@ def test_f32_multi_structure_fit(ctx32, ctx64):
         out[name] = prob.fit_multi(cols, sidx, U0, lbfgs_opts())
         prob.close()
     np.testing.assert_allclose(out["f32"]["loss"], out["f64"]["loss"], rtol=1e-4)
+
+
+def test_penalized_optimization_end_to_end_in_float32():
+    """set_precision("float32") (waveome/utilities.py:34-49) then the whole GPSearch.penalized_optimization():
+    fits run on the float32 path, the float64-only post-fit steps on a float64 context of the same device."""
+    import pandas as pd
+
+    from waveome_amd import utilities as U
+    from waveome_amd.model_search import GPSearch
+
+    rng = np.random.default_rng(4)
+    n = 120
+    X = pd.DataFrame({"t": rng.uniform(0, 5, n), "dose": rng.normal(size=n), "grp": rng.integers(0, 3, n).astype(float)})
+    Y = pd.DataFrame({"a": np.sin(2 * X["t"]) + 0.2 * rng.normal(size=n), "b": 0.8 * X["dose"] + 0.2 * rng.normal(size=n)})
+    out = {}
+    for prec in ("float64", "float32"):
+        U.set_precision(prec)
+        try:
+            gps = GPSearch(X, Y, categorical_vars=["grp"], Y_transform="standardize")
+            gps.penalized_optimization(penalization_factor=None, num_factor_iter=2)
+            out[prec] = {f: (m.fit_result["loss"], m.kernel_name, list(m.feature_importances)) for f, m in gps.models.items()}
+        finally:
+            U.set_precision("float64")
+    for f in ("a", "b"):
+        assert out["float32"][f][1] == out["float64"][f][1]  # same pruned structure
+        assert abs(out["float32"][f][0] - out["float64"][f][0]) <= 1e-3 * max(1.0, abs(out["float64"][f][0]))

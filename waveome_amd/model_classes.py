@@ -34,6 +34,19 @@ def default_context(device: int = 0) -> Context:
     return _default_ctx
 
 
+_ctx64 = {}
+
+
+def float64_context(ctx: Context) -> Context:
+    """Posterior prediction and the component means are float64-only in the C-ABI: on a float32 context they run
+    on a float64 context of the same device (fitting is where float32 pays; these are one evaluation each)."""
+    if ctx.dtype == "float64":
+        return ctx
+    if ctx.device not in _ctx64:
+        _ctx64[ctx.device] = Context(ctx.device, dtype="float64")
+    return _ctx64[ctx.device]
+
+
 class ProblemPool:
     """Device problems on one (X, Y) keyed by kernel structure; `Y` holds every output column."""
 
@@ -120,11 +133,14 @@ class PSVGP:
                     p.prior = prior
 
     # ---- GPU-backed numerics ----------------------------------------------------------
-    def _problem(self, max_batch=2):
+    def _problem(self, max_batch=2, f64=False):
         """(spec, problem) for this model's data and current structure.  Models built by GPSearch share a
         ProblemPool: outputs whose (pruned) kernels have the same structure reuse one device problem that holds
-        every output column, instead of allocating one each (7 + 2 ms per model, as much as a small fit)."""
+        every output column, instead of allocating one each (7 + 2 ms per model, as much as a small fit).
+        f64: the call needs a float64 problem (prediction, component means)."""
         ctx = self._ctx or default_context()
+        if f64:
+            ctx = float64_context(ctx)
         spec = self._spec()
         if self._pool is not None:
             return spec, self._pool.get(spec)
@@ -175,7 +191,7 @@ class PSVGP:
         """Posterior mean / variance of f (model_classes.py:526-534); full_cov is not supported."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full_cov=True is not implemented")
-        spec, prob = self._problem()
+        spec, prob = self._problem(f64=True)
         mean, var = prob.predict(self._col, spec.theta(), include_noise=False, Xnew=self._xnew(Xnew))
         self._release(prob)
         return mean[:, None], var[:, None]
@@ -184,7 +200,7 @@ class PSVGP:
         """Posterior mean / variance of y (model_classes.py:536-544)."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full_cov=True is not implemented")
-        spec, prob = self._problem()
+        spec, prob = self._problem(f64=True)
         mean, var = prob.predict(self._col, spec.theta(), include_noise=True, Xnew=self._xnew(Xnew))
         self._release(prob)
         return mean[:, None], var[:, None]
@@ -316,7 +332,7 @@ class PSVGP:
         reference evaluates in calc_feature_importance_components (utilities.py:614-707); with `only`,
         [full, component 0 alone, 1 alone, ...] as individual_kernel_predictions does for calc_rsquare
         (utilities.py:162-172, 770-780)."""
-        spec, prob = self._problem()
+        spec, prob = self._problem(f64=True)
         comps = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
         # additive component k owns a contiguous run of flattened terms (products of sums expand)
         counts = [len(_expand(k)) for k in comps]
