@@ -226,6 +226,27 @@ def main():
                            for k in GEMM_STAGES if stages[k]["ms"] > 0},
                 "GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in stages.items()
                          if v["bytes"] > 0 and v["ms"] > 0}}
+        if world == 1 and not args.no_breakdown:
+            # BASELINE.json configs[1] beside the throughput row: ONE output, isotropic
+            # SE(all dims) + noise, same N and the same 100-iteration rule - the latency of a single fit
+            from waveome_amd import ModelSpec, kernels as K
+
+            c2 = ModelSpec(K.SquaredExponential(active_dims=list(range(D_HEAD))), D_HEAD, K.GaussianLikelihood(),
+                           K.ConstantMean())
+            p2 = Problem(ctx, X_h, Y_h.T[:, :1], c2, max_batch=1)
+            u2 = c2.unconstrain()[None, :]
+            p2.fit([0], u2, opts)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            r2 = p2.fit([0], u2, opts)
+            ctx.synchronize()
+            dt2 = time.perf_counter() - t2
+            p2.close()
+            out["configs1_single_output"] = {
+                "workload": "C2a: N=2048 D=3, 1 output, SE(all dims) + noise + Constant mean, 100 L-BFGS-B iterations",
+                "fit_seconds": dt2, "fits_per_s": float(r2["nit"][0]) / 100.0 / dt2,
+                "iterations": int(r2["nit"][0]), "evaluations": int(r2["nfev"][0]),
+                "ms_per_evaluation": dt2 * 1e3 / max(1, int(r2["nfev"][0])), "lml": float(r2["lml"][0])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_h, Y_h)
         print(json.dumps(out), flush=True)
