@@ -85,6 +85,60 @@ def pmc_traffic(fits_per_launch):
     return per_fit * fits_per_launch, "profiles/r01_traffic.json (offline rocprofv3 PMC passes, per fit x fits per launch)"
 
 
+def bench_c5(args):
+    """BASELINE configs[4] / SURVEY 8(d) C5: N = 16384, D = 4, 8 outputs, sum_d Matern32[d], float32 (and float64
+    beside it); value-only and value+gradient evaluations timed separately, all 8 outputs in one batch."""
+    from waveome_amd import ModelSpec, kernels as K
+    from waveome_amd.engine import Context, Problem
+
+    N, D, P = 16384, 4, 8
+    rng = np.random.default_rng(9102 + 5)
+    X = rng.uniform(-3, 3, size=(N, D))
+    X = (X - X.mean(0)) / X.std(0, ddof=1)
+    Y = np.stack([np.sin((1.0 + 0.2 * p) * X[:, 0]) + 0.5 * np.sin(2.1 * X[:, 1]) + 0.1 * rng.normal(size=N)
+                  for p in range(P)], axis=1)
+    spec = ModelSpec(K.Sum([K.Matern32(active_dims=[d]) for d in range(D)]), D, K.GaussianLikelihood(), K.ConstantMean())
+    th = spec.theta()
+    th[spec.noise] = 0.3
+    u = np.tile(spec.unconstrain(th), (P, 1))
+    cols = np.arange(P, dtype=np.int32)
+    rows = {}
+    for dtype in ("float32", "float64"):
+        ctx = Context(0, dtype=dtype)
+        prob = Problem(ctx, X, Y, spec, max_batch=P)
+        for _ in range(max(1, args.warmup)):
+            f, g, _ = prob.value_grad(cols, u)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            f, g, _ = prob.value_grad(cols, u)
+        ctx.synchronize()
+        t_vg = (time.perf_counter() - t0) / args.steps
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lml, _ = prob.lml(cols, np.tile(th, (P, 1)))
+        ctx.synchronize()
+        t_v = (time.perf_counter() - t0) / args.steps
+        prob.close()
+        rows[dtype] = {"value_grad_ms": t_vg * 1e3, "value_grad_tflops": P * N ** 3 / t_vg / 1e12,
+                       "value_only_ms": t_v * 1e3, "value_only_tflops": P * N ** 3 / 3 / t_v / 1e12,
+                       "loss": [float(v) for v in f], "grad_max": float(np.max(np.abs(g)))}
+    rel = max(abs(a - b) / abs(b) for a, b in zip(rows["float32"]["loss"], rows["float64"]["loss"]))
+    for r in rows.values():
+        del r["loss"]
+    out = {"metric": "GP value+gradient evaluations/sec (N=16384, fp32)", "value": P / (rows["float32"]["value_grad_ms"] * 1e-3),
+           "unit": "evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
+           "ms_per_step": rows["float32"]["value_grad_ms"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C5: N=16384 D=4, 8 outputs in one batch, sum_d Matern32[d], sigma^2=0.3; "
+                                  "algorithmic FLOP: N^3 per value+gradient, N^3/3 per value-only evaluation"},
+           "float32": rows["float32"], "float64": rows["float64"], "loss_rel_err_f32_vs_f64": rel,
+           "roofline": {"bound": "mfma", "kernel": "all stages of one value+gradient evaluation",
+                        "achieved": rows["float32"]["value_grad_tflops"], "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": rows["float32"]["value_grad_tflops"] / 157.3, "traffic": None}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +148,11 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="fits in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed per-stage step")
+    ap.add_argument("--config", default="headline", choices=["headline", "c5"],
+                    help="headline: the BASELINE metric (default).  c5: BASELINE configs[4], N=16384 float32 stress")
     args = ap.parse_args()
+    if args.config == "c5":
+        return bench_c5(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
