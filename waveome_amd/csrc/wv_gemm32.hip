@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
     const float* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;
     if (kc0 + KC > wkb && kc0 < wke) {
-#pragma unroll 2
+#pragma unroll
       for (int s = 0; s < KC / 4; ++s) {
         float af[4], bf[4];
 #pragma unroll
