@@ -308,3 +308,24 @@ def test_precision_switch_validates_its_argument():
     U.set_precision("float32")
     assert U.get_precision() == "float32"
     U.set_precision("float64")
+
+
+def test_replace_kernel_variables_and_randomize_params():
+    from waveome_amd.model_classes import PSVGP
+    from waveome_amd.utilities import replace_kernel_variables
+
+    assert replace_kernel_variables("categorical[2]*lin[0]+squared_exponential[1]", ["t", "dose", "grp"]) == \
+        "categorical[grp]*lin[t]+squared_exponential[dose]"
+    rng = np.random.default_rng(0)
+    m = PSVGP(rng.normal(size=(10, 2)), rng.normal(size=(10, 1)),
+              kernel=K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])]))
+    frozen = m.kernel.kernels[1].variance
+    K.set_trainable(frozen, False)
+    m.randomize_params(random_seed=3)
+    a = m._spec().theta()
+    m.randomize_params(random_seed=3)
+    np.testing.assert_array_equal(a, m._spec().theta())
+    assert frozen.value == 1.0 and np.all(a[:2] > 0)  # frozen parameters keep their value, positives stay positive
+    np.random.seed(3)
+    u = np.random.normal(size=m._spec().n_trainable)
+    np.testing.assert_allclose(m._spec().unconstrain(), u, rtol=1e-9, atol=1e-9)

@@ -248,6 +248,15 @@ class PSVGP:
     def _restart_points(self, num_restart, loc=0.0, scale=1.0, random_seed=None):
         return restart_points(self._spec().n_trainable, num_restart, loc, scale, random_seed)
 
+    def randomize_params(self, loc: float = 0.0, scale: float = 1.0, random_seed=None):
+        """Assign every trainable parameter a value whose unconstrained coordinate is drawn from N(loc, scale)
+        under `np.random.seed(random_seed)` (model_classes.py:181-234)."""
+        np.random.seed(random_seed)
+        spec = self._spec()
+        u = np.random.normal(loc=loc, scale=scale, size=spec.n_trainable)
+        spec.assign_theta(spec.constrain(u))
+        return None
+
     def random_restart_optimize(self, data=None, num_restart=5, randomize_kwargs={}, optimize_kwargs={}):
         """`num_restart` randomised fits in one batched call; keeps the one with the highest
         `maximum_log_likelihood_objective` (no prior term, :511-519)."""

@@ -75,6 +75,14 @@ def calc_rsquare(m, data=None):
     return rsq
 
 
+def replace_kernel_variables(k_name, col_names):
+    """Indexed kernel names -> column names: "[i]" becomes "[col_names[i]]" (waveome/utilities.py:262-278)."""
+    new_k_name = k_name
+    for i, c in enumerate(col_names):
+        new_k_name = new_k_name.replace("[" + str(i) + "]", "[" + c + "]")
+    return new_k_name
+
+
 def print_kernel_names(kernel, with_idx=False):
     names = []
     if kernel is None:
