@@ -1,0 +1,78 @@
+"""The sharded (N > 1) paths of GPSearch on real GPU code: two ranks over gloo, both on GPU 0 (the 1-GPU test box),
+must reproduce the single-process results bit for bit - tasks are independent and a slot's arithmetic does not
+depend on its batch (tests/test_gpu_parity.py::test_results_do_not_depend_on_batch_composition)."""
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, pickle, sys
+import numpy as np, pandas as pd
+sys.path.insert(0, os.environ["WV_ROOT"])
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
+from waveome_amd import kernels as K
+from waveome_amd.model_search import GPSearch
+rng = np.random.default_rng(3)
+n = 60
+X = pd.DataFrame({"t": rng.normal(size=n), "dose": rng.normal(size=n), "grp": (np.arange(n) % 3).astype(float)})
+Y = pd.DataFrame({f"y{p}": np.sin((1 + 0.3 * p) * X["t"]) + 0.4 * (p % 2) * X["dose"] + 0.2 * rng.normal(size=n)
+                  for p in range(5)})
+out = {}
+gps = GPSearch(X, Y, categorical_vars=["grp"])
+gps.penalized_optimization(penalization_factor=5.0)
+out["pen"] = {f: (m.fit_result["loss"], m.kernel_name) for f, m in gps.models.items()}
+tab = gps.kernel_sweep({"se": K.SquaredExponential(active_dims=[0]),
+                        "lin+cat": K.Sum([K.Lin(active_dims=[1]), K.Categorical(active_dims=[2])])}, keep_models=False)
+out["sweep"] = tab[["loss", "bic", "nit"]].to_numpy()
+gps.run_search(kernels=[K.SquaredExponential(), K.Lin()], max_depth=2, keep_only_best=False)
+out["search"] = {f: {n_: m["bic"] for n_, m in gps.search_info[f]["models"].items()} for f in gps.out_names}
+out["best"] = {f: gps.search_info[f]["best_model"] for f in gps.out_names}
+with open(os.environ["WV_OUT"] + "." + os.environ.get("RANK", "s"), "wb") as fh:
+    pickle.dump(out, fh)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(env_extra, out):
+    env = dict(os.environ, WV_ROOT=ROOT, WV_OUT=out, OMP_NUM_THREADS="2", **env_extra)
+    return subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def test_two_ranks_reproduce_the_single_process_results(tmp_path):
+    out = str(tmp_path / "res")
+    p = _run({}, out)
+    log, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, log.decode()[-3000:]
+    port = _free_port()
+    procs = [_run({"RANK": str(r), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, out)
+             for r in range(2)]
+    for q in procs:
+        log, _ = q.communicate(timeout=600)
+        assert q.returncode == 0, log.decode()[-3000:]
+    single = pickle.load(open(out + ".s", "rb"))
+    for r in range(2):
+        got = pickle.load(open(out + f".{r}", "rb"))
+        assert got["pen"] == single["pen"]
+        np.testing.assert_array_equal(got["sweep"], single["sweep"])
+        assert got["search"] == single["search"] and got["best"] == single["best"]
