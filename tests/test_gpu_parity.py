@@ -680,3 +680,43 @@ def test_value_only_path_agrees_with_value_and_gradient_path(ctx, N):
     if N <= 1000:
         want = [o.lml(ms.to_dict(), ms.constrain(U[t]), X, Y[:, cols[t]]) for t in range(3)]
         np.testing.assert_allclose(lml, want, rtol=1e-10, atol=1e-9)
+
+
+def test_multi_structure_fit_with_priors_and_a_failing_task(ctx):
+    """wv_fit_multi with per-task Horseshoe scales, and one task whose data make every evaluation non-finite:
+    that task reports a failure status and a non-finite loss, its neighbours in the batch are unaffected."""
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(41, 90, D=4, P=3)
+    Y = Y.copy()
+    Y[:, 2] = np.nan  # column 2: the residual is NaN, so the objective is never finite
+    specs = [_with_priors(ModelSpec(K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])]), 4,
+                                    K.GaussianLikelihood(), K.ConstantMean())),
+             _with_priors(ModelSpec(K.Matern52(active_dims=[0, 1]), 4, K.GaussianLikelihood(), K.ConstantMean()))]
+    cols = np.array([0, 1, 2, 0], dtype=np.int32)
+    sidx = np.array([0, 1, 0, 1], dtype=np.int32)
+    scale = np.array([1.0, 0.1, 1.0, 0.5])
+    width = max(sp.n_trainable for sp in specs)
+    U0 = np.zeros((4, width))
+    for t, si in enumerate(sidx):
+        U0[t, :specs[si].n_trainable] = specs[si].unconstrain()
+    opts = lbfgs_opts(maxiter=30)
+    prob = Problem(ctx, X, Y, specs, max_batch=4)
+    r = prob.fit_multi(cols, sidx, U0, opts, prior_scale=scale)
+    prob.close()
+    assert not np.isfinite(r["loss"][2]) or r["status"][2] != 0
+    good = [0, 1, 3]
+    assert np.all(np.isfinite(r["loss"][good]))
+    for t in good:  # each good task equals the same task fitted alone
+        sp = specs[sidx[t]]
+        solo = Problem(ctx, X, Y, sp, max_batch=1)
+        rs = solo.fit(cols[t:t + 1], U0[t:t + 1, :sp.n_trainable], opts, prior_scale=scale[t:t + 1])
+        solo.close()
+        assert rs["loss"][0] == r["loss"][t] and rs["nit"][0] == r["nit"][t]
+        # and the objective is the oracle's at the returned point
+        d = sp.to_dict()
+        for prm in d["params"]:
+            if prm["prior_scale"] is not None:
+                prm["prior_scale"] = float(scale[t])
+        want, _ = o.objective(d, r["u"][t, :sp.n_trainable], X, Y[:, cols[t]])
+        assert abs(want - r["loss"][t]) <= 1e-9 * max(1.0, abs(want))
