@@ -579,6 +579,17 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 //   M21 = -M22 T                      (contraction k <= row)
 // L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
 // ---------------------------------------------------------------------------------------
+// Tile width for a product with a rows x cols output over nb matrices: 128-wide tiles unless so few of them
+// exist that most of the 512 resident workgroup slots would idle - then 64-wide tiles double the parallelism
+// (the small-batch, large-N end: the tail of a job, a single fit).  WV_BN_FILL=0 restores 128 everywhere.
+static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
+  if (cols <= 64) return 64;
+  static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 512; }();
+  int64_t tiles = ((rows + 127) / 128) * ((cols + 127) / 128);
+  if (lower_only) tiles = (tiles + (rows + 127) / 128) / 2;
+  return tiles * nb < fill ? 64 : 128;
+}
+
 template <typename R>
 static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
   if (n == NB) {
@@ -602,7 +613,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
     p.timer.begin(st, ST_CHOL_TRSM);
-    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, true, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
@@ -613,7 +624,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
     a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
     p.timer.begin(st, ST_CHOL_TRAIL);
-    launch_gemm(st, a, false, false, h2 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, pick_bn(h2, h2, nb, true));
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
@@ -624,7 +635,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.C = K0 + (o + h1) * Np + o;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.klo_mode = 2;
     p.timer.begin(st, ST_TRTRI_A);
-    launch_gemm(st, a, false, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
     p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
@@ -637,7 +648,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.CT = MT0 + o * Np + (o + h1); a.sCT = mat; a.ldct = (int)Np; a.tout = 2;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h2; a.khi_mode = 1; a.alpha = -1.0;
     p.timer.begin(st, ST_TRTRI_B);
-    launch_gemm(st, a, false, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
     p.timer.work(ST_TRTRI_B, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
@@ -684,7 +695,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
     p.timer.begin(st, ST_CHOL_TRSM);
-    launch_gemm(st, a, true, false, h1 > 64 ? 128 : 64);
+    launch_gemm(st, a, true, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
@@ -699,7 +710,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
     a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
     p.timer.begin(st, ST_CHOL_TRAIL);
-    launch_gemm(st, a, false, false, h2 > 64 ? 128 : 64);
+    launch_gemm(st, a, false, false, pick_bn(h2, h2, nb, true));
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
   }
@@ -727,7 +738,7 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
   p.timer.begin(st, ST_LAUUM);
-  launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
+  launch_gemm(st, a, false, false, pick_bn(Np, Np, nb, true));
   p.timer.end(st);
   p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
 }
