@@ -139,6 +139,39 @@ def bench_c5(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_c2(args):
+    """BASELINE configs[1] / SURVEY 8(d) C2a beside the throughput row: ONE output, isotropic SE(all dims) + noise,
+    same N and the same 100-iteration rule - the latency of a single fit (kept out of the default run so that the
+    default command's kernel statistics cover the headline workload only)."""
+    from waveome_amd import ModelSpec, kernels as K
+    from waveome_amd.engine import Context, Problem, lbfgs_opts
+
+    X_h, Y_h = make_inputs(8)
+    ctx = Context(0)
+    opts = lbfgs_opts(maxiter=100, maxfun=100000, ftol=0.0, gtol=0.0)
+    c2 = ModelSpec(K.SquaredExponential(active_dims=list(range(D_HEAD))), D_HEAD, K.GaussianLikelihood(),
+                   K.ConstantMean())
+    p2 = Problem(ctx, X_h, Y_h.T[:, :1], c2, max_batch=1)
+    u2 = c2.unconstrain()[None, :]
+    for _ in range(max(1, args.warmup)):
+        p2.fit([0], u2, opts)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        r2 = p2.fit([0], u2, opts)
+    ctx.synchronize()
+    dt2 = (time.perf_counter() - t2) / args.steps
+    p2.close()
+    out = {"metric": "GP single-output fit latency (N=2048, fp64)", "value": dt2, "unit": "s", "n_gpus": 1,
+           "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt2 * 1e3, "higher_is_better": False,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "C2a: N=2048 D=3, 1 output, SE(all dims) + noise + Constant mean, L-BFGS-B "
+                                  "(maxiter=100, ftol=gtol=0)",
+                      "iterations": int(r2["nit"][0]), "evaluations": int(r2["nfev"][0]),
+                      "ms_per_evaluation": dt2 * 1e3 / max(1, int(r2["nfev"][0])), "lml": float(r2["lml"][0])}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,11 +181,14 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="fits in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed per-stage step")
-    ap.add_argument("--config", default="headline", choices=["headline", "c5"],
-                    help="headline: the BASELINE metric (default).  c5: BASELINE configs[4], N=16384 float32 stress")
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c5"],
+                    help="headline: the BASELINE metric (default).  c2: BASELINE configs[1], one output, single-fit "
+                         "latency.  c5: BASELINE configs[4], N=16384 float32 stress")
     args = ap.parse_args()
     if args.config == "c5":
         return bench_c5(args)
+    if args.config == "c2":
+        return bench_c2(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,27 +320,6 @@ def main():
                            for k in GEMM_STAGES if stages[k]["ms"] > 0},
                 "GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in stages.items()
                          if v["bytes"] > 0 and v["ms"] > 0}}
-        if world == 1 and not args.no_breakdown:
-            # BASELINE.json configs[1] beside the throughput row: ONE output, isotropic
-            # SE(all dims) + noise, same N and the same 100-iteration rule - the latency of a single fit
-            from waveome_amd import ModelSpec, kernels as K
-
-            c2 = ModelSpec(K.SquaredExponential(active_dims=list(range(D_HEAD))), D_HEAD, K.GaussianLikelihood(),
-                           K.ConstantMean())
-            p2 = Problem(ctx, X_h, Y_h.T[:, :1], c2, max_batch=1)
-            u2 = c2.unconstrain()[None, :]
-            p2.fit([0], u2, opts)
-            ctx.synchronize()
-            t2 = time.perf_counter()
-            r2 = p2.fit([0], u2, opts)
-            ctx.synchronize()
-            dt2 = time.perf_counter() - t2
-            p2.close()
-            out["configs1_single_output"] = {
-                "workload": "C2a: N=2048 D=3, 1 output, SE(all dims) + noise + Constant mean, 100 L-BFGS-B iterations",
-                "fit_seconds": dt2, "fits_per_s": float(r2["nit"][0]) / 100.0 / dt2,
-                "iterations": int(r2["nit"][0]), "evaluations": int(r2["nfev"][0]),
-                "ms_per_evaluation": dt2 * 1e3 / max(1, int(r2["nfev"][0])), "lml": float(r2["lml"][0])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_h, Y_h)
         print(json.dumps(out), flush=True)

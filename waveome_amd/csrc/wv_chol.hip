@@ -738,7 +738,8 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
   p.timer.begin(st, ST_LAUUM);
-  launch_gemm(st, a, false, false, pick_bn(Np, Np, nb, true));
+  // (always 128-wide tiles: one launch per evaluation, and it keeps this product on its own kernel symbol)
+  launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
   p.timer.end(st);
   p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
 }
