@@ -188,6 +188,248 @@ void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
 }
 
 // ---------------------------------------------------------------------------------------
+// potrf128: the whole recursion node of size 128 in ONE kernel - factor + invert the 64 x 64 block at (o, o),
+// S = A21 M11', A22 -= S S', T = S M11, factor + invert the Schur complement, M21 = -M22 T - instead of two
+// leaf launches and four 64^3 GEMM launches.  Same thread layout as potrf_diag_kernel (16 x 16 threads, 4 x 4
+// elements each); the three 64^3 products run on the fp64 VALU out of LDS (2 MFLOP per matrix: noise next to the
+// launches they replace, which are pure latency at this size).  Writes M and M' of the 128 block and the two
+// log-det partials; K's own blocks are dead after this node and are not written back.
+// ---------------------------------------------------------------------------------------
+template <typename R>
+__device__ inline bool factor64(R (&a)[4][4], R (*colbuf)[NB], int ty, int tx) {
+  bool anybad = false;
+  for (int jb = 0; jb < 16; ++jb) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * jb + jj;
+      R* cb = colbuf[j & 1];
+      if (tx == jb && ty >= jb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cb[4 * ty + r] = a[r][jj];
+      }
+      __syncthreads();
+      R piv = cb[j];
+      const bool ok = piv > R(0);
+      if (!ok) { piv = 1; anybad = true; }
+      const R inv = rsq(piv);
+      if (ty >= tx && tx >= jb) {
+        R lr[4], lc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lr[r] = cb[4 * ty + r] * inv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lc[c] = cb[4 * tx + c] * inv;
+        if (tx == jb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r][jj] = (ty == jb && r == jj) ? piv * inv : lr[r];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c > jj) a[r][c] -= lr[r] * lc[c];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[r][c] -= lr[r] * lc[c];
+        }
+      }
+    }
+  }
+  return anybad;
+}
+
+// L (lower, LDS) -> X = L^-1 (LDS; must be zero on entry), T scratch.  Ends with a barrier.
+template <typename R>
+__device__ inline void invert64(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
+  if (tid < 64) {
+    const int blk = tid >> 2, c = tid & 3, o = blk * 4;
+    X[(o + c) * DS + o + c] = R(1) / L[(o + c) * DS + o + c];
+    for (int i = c + 1; i < 4; ++i) {
+      R s = 0;
+      for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
+      X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
+    }
+  }
+  __syncthreads();
+  inv_level<4>(L, X, T, tid);
+  inv_level<8>(L, X, T, tid);
+  inv_level<16>(L, X, T, tid);
+  inv_level<32>(L, X, T, tid);
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* __restrict__ Mall, R* __restrict__ MTall,
+                                                       double* __restrict__ logdet, int32_t* __restrict__ status,
+                                                       int64_t Npad, int nblk, int slot0, int o) {
+  __shared__ R L[NB * DS];
+  __shared__ R X[NB * DS];
+  __shared__ R T[NB * DS];
+  __shared__ R colbuf[2][NB];
+  __shared__ int bad;
+  const int b = slot0 + blockIdx.x;
+  const int64_t mat = Npad * Npad;
+  const R* K = Kall + (int64_t)b * mat;
+  R* M = Mall + (int64_t)b * mat;
+  R* MT = MTall + (int64_t)b * mat;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int64_t o1 = o, o2 = o + NB;
+  if (tid == 0) bad = 0;
+
+  auto stage_L_and_logdet = [&](R (&a)[4][4], bool anybad, int blk) {  // L -> LDS (upper zeroed), log-det partial
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = 4 * ty + r, jc = 4 * tx + c;
+        L[i * DS + jc] = (jc <= i) ? a[r][c] : R(0);
+      }
+    if (anybad) bad = 1;  // (same value from every writer)
+    __syncthreads();
+    if (tid < 64) {
+      double v = log((double)L[tid * DS + tid]);
+#pragma unroll
+      for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
+      if (tid == 0) logdet[(int64_t)b * nblk + blk] = v;
+    }
+  };
+  auto write_inverse_block = [&](int64_t row0, int64_t col0) {  // X -> M[row0.., col0..] and its transpose into M'
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * ty + r;
+      const R v[4] = {X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1], X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]};
+      st4(M + (row0 + i) * Npad + col0 + 4 * tx, v);
+      const R w[4] = {X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i], X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]};
+      st4(MT + (col0 + i) * Npad + row0 + 4 * tx, w);
+    }
+  };
+
+  // ---- A11: factor, invert -> M11 ----
+  R a[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ld4(K + (o1 + 4 * ty + r) * Npad + o1 + 4 * tx, a[r]);
+  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
+  bool anybad = factor64<R>(a, colbuf, ty, tx);
+  stage_L_and_logdet(a, anybad, o / NB);
+  invert64<R>(L, X, T, tid);  // X = M11
+  write_inverse_block(o1, o1);
+
+  // ---- S = A21 M11'  (A21 staged in T; M11 lower: k <= column) ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    R v[4];
+    ld4(K + (o2 + 4 * ty + r) * Npad + o1 + 4 * tx, v);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[(4 * ty + r) * DS + 4 * tx + c] = v[c];
+  }
+  __syncthreads();
+  R sacc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sacc[r][c] = 0;
+  for (int k = 0; k < 4 * tx + 4; ++k) {
+    R ar[4], mc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ar[r] = T[(4 * ty + r) * DS + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mc[c] = X[(4 * tx + c) * DS + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sacc[r][c] += ar[r] * mc[c];
+  }
+  __syncthreads();  // every read of L (log-det, inversion) and of T (A21) is done
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = sacc[r][c];  // L now holds S
+  __syncthreads();
+
+  // ---- A22 -= S S'  and  T2 = S M11 (kept in registers) ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ld4(K + (o2 + 4 * ty + r) * Npad + o2 + 4 * tx, a[r]);
+  R t2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t2[r][c] = 0;
+  for (int k = 0; k < NB; ++k) {
+    R sr[4], sc[4], mk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sr[r] = L[(4 * ty + r) * DS + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sc[c] = L[(4 * tx + c) * DS + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mk[c] = X[k * DS + 4 * tx + c];  // M11[k][col] (zero above the diagonal)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[r][c] -= sr[r] * sc[c];
+        t2[r][c] += sr[r] * mk[c];
+      }
+  }
+  __syncthreads();  // S and M11 are no longer needed in LDS
+
+  // ---- Schur complement: factor, invert -> M22 ----
+  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
+  anybad = factor64<R>(a, colbuf, ty, tx);
+  stage_L_and_logdet(a, anybad, o / NB + 1);
+  invert64<R>(L, X, T, tid);  // X = M22
+  write_inverse_block(o2, o2);
+  if (tid == 0 && bad) status[b] = 1;
+
+  // ---- M21 = -M22 T2  (T2 staged in T; M22 lower: k <= row) ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T[(4 * ty + r) * DS + 4 * tx + c] = t2[r][c];
+  __syncthreads();
+  R macc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) macc[r][c] = 0;
+  for (int k = 0; k < 4 * ty + 4; ++k) {
+    R mr[4], tc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mr[r] = X[(4 * ty + r) * DS + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tc[c] = T[k * DS + 4 * tx + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) macc[r][c] -= mr[r] * tc[c];
+  }
+  // M21 -> M[(o2 + i)][o1 + j] and M'[(o1 + j)][o2 + i]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) st4(M + (o2 + 4 * ty + r) * Npad + o1 + 4 * tx, macc[r]);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = macc[r][c];  // stage for the transposed store
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 4 * ty + r;  // row of M' block = column of M21
+    const R w[4] = {L[(4 * tx) * DS + j], L[(4 * tx + 1) * DS + j], L[(4 * tx + 2) * DS + j], L[(4 * tx + 3) * DS + j]};
+    st4(MT + (o1 + j) * Npad + o2 + 4 * tx, w);
+  }
+}
+
+void launch_potrf128(Problem& p, hipStream_t st, int slot0, int nb, int o) {
+  p.timer.begin(st, ST_POTRF_DIAG);
+  if (p.f32)
+    hipLaunchKernelGGL(potrf128_kernel<float>, dim3(nb), dim3(256), 0, st, p.Kbuf32, p.Mbuf32, p.MTbuf32, p.dlogdet,
+                       p.dstatus, p.Npad, p.nblk(), slot0, o);
+  else
+    hipLaunchKernelGGL(potrf128_kernel<double>, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
+                       p.dstatus, p.Npad, p.nblk(), slot0, o);
+  p.timer.end(st);
+}
+
+// ---------------------------------------------------------------------------------------
 // residual r = y[col] - c (zero on padded rows); also clears the slot's status word
 // ---------------------------------------------------------------------------------------
 __global__ void resid_kernel(const DevSpec* __restrict__ specs, const int32_t* __restrict__ slot_spec,
@@ -596,6 +838,11 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     launch_potrf_diag(p, st, slot0, nb, (int)o);
     return;
   }
+  static const bool fuse128 = [] { const char* e = getenv("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
+  if (n == 2 * NB && fuse128) {  // the whole node in one kernel
+    launch_potrf128(p, st, slot0, nb, (int)o);
+    return;
+  }
   const int64_t Np = p.Npad, mat = Np * Np;
   const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
   const MatBufs<R> mb = mat_bufs<R>(p);
@@ -674,6 +921,15 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.begin(st, ST_SOLVE);
     hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(NB / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o,
                        (int64_t)NB, slot0);
+    p.timer.end(st);
+    return;
+  }
+  static const bool fuse128 = [] { const char* e = getenv("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
+  if (n == 2 * NB && fuse128) {  // fused node: M of the whole 128 block is available, one forward substitution
+    launch_potrf128(p, st, slot0, nb, (int)o);
+    p.timer.begin(st, ST_SOLVE);
+    hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(2 * NB / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o,
+                       (int64_t)(2 * NB), slot0);
     p.timer.end(st);
     return;
   }
