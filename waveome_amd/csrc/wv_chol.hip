@@ -1,13 +1,16 @@
-// Blocked factorisation / inversion schedules and the small kernels around the MFMA GEMMs.
+// Factorisation / inversion schedules and the small kernels around the MFMA GEMMs.
 //
 // Per evaluation and batch slot (reference: tf.linalg.cholesky + triangular_solve forward and
 // reverse mode under gpflow's log marginal likelihood, waveome/model_types_DEPR.py:49-56):
-//   cholesky: K_y = L L'    right-looking, two-level blocking (outer 256, inner 64):
-//             potrf_diag (64x64 in LDS, also writes inv(L_jj) and log-det partials)
-//             -> TRSM as GEMM with inv(L_jj) -> panel update (K = 64) -> trailing SYRK (K = 256)
-//   trtri:    M = L^-1      by block columns right to left:  P = M22 L21,  M21 = -P M_jj
-//   lauum:    K_y^-1 = M' M one launch, lower tiles, contraction over rows >= tile row
-//   solve:    z = M r, alpha = M' z (HBM-bound matvecs), reduce: LML and gradient assembly.
+//   factor_inverse     value + gradient: recursive K_y = L L' together with M = L^-1 (fi_node); leaves are
+//                      potrf_diag (64 x 64) and potrf128 (a whole 128-node in one kernel)
+//   factor_value_only  value only: the same recursion without the inverse of the whole matrix, forward
+//                      substitution z = L^-1 r fused in (fv_node), 0.38 N^3 instead of 0.67 N^3
+//   lauum              K_y^-1 = M' M, one launch, lower tiles, contraction over rows >= tile row
+//   solve              z = M r, alpha = M' z (HBM-bound matvecs); reduce: LML and gradient assembly
+//   cholesky / trtri   the first, right-looking schedule (outer 256, inner 64 panels); still used by the
+//                      stand-alone factor of wv_whitened_means and by wv_dbg_stage(what = 0)
+// Storage type R is double, or float on a float32 context; vectors and reductions are always double.
 #include "wv_device.hpp"
 
 namespace wv {
