@@ -967,17 +967,37 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
   launch_gram_masked(p, st, g.slot0, 1, all, jitter);
   cholesky(p, st, g.slot0, 1);
   launch_trmv(p, st, p.Kbuf, p.dalpha, p.dr, g.slot0, 1, true);
-  std::vector<double> host(p.N);
-  for (int m = 0; m < n_masks; ++m) {
-    launch_gram_masked(p, st, g.slot0, 1, term_masks[m] & all, jitter);
-    cholesky(p, st, g.slot0, 1);
-    launch_trmv(p, st, p.Kbuf, p.dr, p.dz, g.slot0, 1, false);
-    WV_HIP_TRY(hipMemcpyAsync(host.data(), out, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
-    WV_HIP_TRY(hipStreamSynchronize(st));
-    for (int64_t i = 0; i < p.N; ++i) means_out[(int64_t)m * p.N + i] = host[i] + c;
+  // The masked Gram matrices are independent given q_mu: factor them as ONE batch over the group's slots
+  // (chunks of nslots masks) instead of one latency-bound factorisation after the other.
+  const int np_ = p.np_stride;
+  const int cap = g.nslots;
+  for (int s = 1; s < std::min(cap, (int)n_masks); ++s) {  // every slot gets the parameter row and q_mu
+    std::memcpy(g.h_theta + (size_t)s * np_, g.h_theta, sizeof(double) * np_);
+    WV_HIP_TRY(hipMemcpyAsync(p.dr + (int64_t)(g.slot0 + s) * p.Npad, p.dr + (int64_t)g.slot0 * p.Npad,
+                              sizeof(double) * p.Npad, hipMemcpyDeviceToDevice, st));
   }
-  int32_t bad = 0;
-  WV_HIP_TRY(hipMemcpy(&bad, p.dstatus + g.slot0, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (cap > 1 && n_masks > 1)
+    WV_HIP_TRY(hipMemcpyAsync(p.dtheta + (int64_t)g.slot0 * np_, g.h_theta,
+                              sizeof(double) * np_ * std::min(cap, (int)n_masks), hipMemcpyHostToDevice, st));
+  // status words only ever get set: slot 0 still carries the verdict on the q_mu factor above
+  if (cap > 1) WV_HIP_TRY(hipMemsetAsync(p.dstatus + g.slot0 + 1, 0, sizeof(int32_t) * (cap - 1), st));
+  std::vector<double> host((size_t)cap * p.Npad);
+  int32_t bad_any = 0;
+  for (int m0 = 0; m0 < n_masks; m0 += cap) {
+    const int nbm = std::min(cap, n_masks - m0);
+    for (int s = 0; s < nbm; ++s) launch_gram_masked(p, st, g.slot0 + s, 1, term_masks[m0 + s] & all, jitter);
+    cholesky(p, st, g.slot0, nbm);
+    launch_trmv(p, st, p.Kbuf, p.dr, p.dz, g.slot0, nbm, false);
+    WV_HIP_TRY(hipMemcpyAsync(host.data(), p.dz + (int64_t)g.slot0 * p.Npad, sizeof(double) * p.Npad * nbm,
+                              hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipMemcpyAsync(g.h_status, p.dstatus + g.slot0, sizeof(int32_t) * nbm, hipMemcpyDeviceToHost, st));
+    WV_HIP_TRY(hipStreamSynchronize(st));
+    for (int s = 0; s < nbm; ++s) {
+      bad_any |= g.h_status[s];
+      for (int64_t i = 0; i < p.N; ++i) means_out[(int64_t)(m0 + s) * p.N + i] = host[(size_t)s * p.Npad + i] + c;
+    }
+  }
+  const int32_t bad = bad_any;
   WV_HIP_TRY(hipGetLastError());
   (void)K0; (void)q_mu;
   if (bad) {

@@ -50,7 +50,7 @@ def float64_context(ctx: Context) -> Context:
 class ProblemPool:
     """Device problems on one (X, Y) keyed by kernel structure; `Y` holds every output column."""
 
-    def __init__(self, ctx, X, Y, max_batch=2):
+    def __init__(self, ctx, X, Y, max_batch=8):  # 8 slots: the leave-one-component-out Gram matrices factor as a batch
         self.ctx, self.X, self.Y, self.max_batch = ctx, X, Y, max_batch
         self._probs = {}
 
