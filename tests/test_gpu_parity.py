@@ -720,3 +720,57 @@ def test_multi_structure_fit_with_priors_and_a_failing_task(ctx):
                 prm["prior_scale"] = float(scale[t])
         want, _ = o.objective(d, r["u"][t, :sp.n_trainable], X, Y[:, cols[t]])
         assert abs(want - r["loss"][t]) <= 1e-9 * max(1.0, abs(want))
+
+
+def _random_tree(rng, depth):
+    kinds = ["se", "m12", "m32", "m52", "per", "lin", "poly", "cat", "const"]
+    if depth == 0 or rng.random() < 0.3:
+        kind = kinds[rng.integers(len(kinds))]
+        d = int(rng.integers(0, 3))
+        v, ell, per = (float(rng.uniform(0.4, 2.0)) for _ in range(3))
+        if kind in ("se", "m12", "m32", "m52"):
+            cls = {"se": K.SquaredExponential, "m12": K.Matern12, "m32": K.Matern32, "m52": K.Matern52}[kind]
+            dims = sorted({d, int(rng.integers(0, 3))})
+            return cls(variance=v, lengthscales=ell, active_dims=dims)
+        if kind == "per":
+            return K.Periodic(K.SquaredExponential(variance=v, lengthscales=ell, active_dims=[d]), period=per)
+        if kind == "lin":
+            return K.Lin(active_dims=[d], variance=v)
+        if kind == "poly":
+            return K.Poly(active_dims=[d], variance=v, offset=ell, degree=int(rng.integers(2, 4)))
+        if kind == "cat":
+            return K.Categorical(active_dims=[3], variance=v)
+        return K.Constant(variance=v)
+    subs = [_random_tree(rng, depth - 1) for _ in range(int(rng.integers(2, 4)))]
+    return K.Sum(subs) if rng.random() < 0.5 else K.Product(subs)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_kernel_trees_match_oracle(ctx, seed):
+    """Seeded random Sum / Product trees over every kernel type (nested sums inside products are distributed
+    by the spec encoder): Gram matrix, loss and gradient against the oracle."""
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(100 + seed)
+    kern = _random_tree(rng, 2)
+    ms = _with_priors(ModelSpec(kern, 4, K.GaussianLikelihood(), K.ConstantMean()))
+    if sum(len(t) for t in ms.terms) > 128 or len(ms.terms) > 64 or max(len(t) for t in ms.terms) > 4:
+        pytest.skip("beyond the device limits of one spec (64 terms, 128 factors, 4 factors per product)")
+    X, Y = _data(50 + seed, 130)
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    d = ms.to_dict()
+    th = ms.theta()
+    Kg = prob.gram(th)
+    Ko = o.gram(d, th, X) + th[ms.noise] * np.eye(len(X))
+    np.testing.assert_allclose(Kg, Ko, rtol=1e-12, atol=1e-12 * max(1.0, np.max(np.abs(Ko))))
+    U = np.stack([ms.unconstrain() + 0.2 * rng.normal(size=ms.n_trainable) for _ in range(2)])
+    cols = np.array([0, 2], dtype=np.int32)
+    loss, grad, st = prob.value_grad(cols, U)
+    prob.close()
+    for b in range(2):
+        fo, go = o.objective(d, U[b], X, Y[:, cols[b]])
+        if not np.isfinite(fo):
+            assert st[b] != 0 or not np.isfinite(loss[b])
+            continue
+        assert loss[b] == pytest.approx(fo, rel=1e-9, abs=1e-8)
+        np.testing.assert_allclose(grad[b], go, rtol=1e-6, atol=1e-6 * max(1.0, np.max(np.abs(go))))
