@@ -173,7 +173,10 @@ int32_t wv_ctx_synchronize(wv_ctx* ctx);
  * workspace for `max_batch` fits in flight (two N x N matrices per slot).
  * Replaces PSVGP.__init__ data staging, waveome/model_classes.py:123-140.
  * x_is_device / y_is_device != 0: the pointers are device pointers on this
- * context's GPU (e.g. buffers an RCCL broadcast filled); they are copied D2D. */
+ * context's GPU (e.g. buffers an RCCL broadcast filled); they are copied D2D.  * Limits of one structure on the device (WV_E_UNSUPPORTED otherwise): D <= 32 input columns, <= 64 additive
+ * terms, <= 128 factors in total, <= 4 factors per product, <= 64 staged features (a Periodic factor uses
+ * three per active column).  The reference's full_kernel_build and kernel search stay far inside them
+ * (two-way products only, waveome/model_search.py:2463-2466). */
 int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
                           int32_t P, const wv_kernel_spec* spec, int32_t max_batch,
                           int32_t x_is_device, int32_t y_is_device, wv_problem** out);
