@@ -290,21 +290,37 @@ def lml_and_grad(spec, theta, X, y):
     """(LML, dLML/dtheta over ALL params, constrained coordinates).
 
     dLML/dtheta_p = 1/2 tr(W dK/dtheta_p), W = alpha alpha^T - Ky^-1;
-    dLML/dsigma^2 = 1/2 tr(W); dLML/dc = 1^T alpha  (SURVEY.md Appendix A)."""
+    dLML/dsigma^2 = 1/2 tr(W); dLML/dc = 1^T alpha  (SURVEY.md Appendix A).
+    K_y^-1 comes from LAPACK dpotri on the Cholesky factor and the traces are accumulated term by term
+    (no dK/dtheta matrix outlives its term), which is how a competent CPU implementation would do it."""
     X = np.asarray(X, dtype=np.float64)
     N = X.shape[0]
-    Ky = gram(spec, theta, X)
+    # every factor is evaluated once; K_y is assembled from the same values the gradient uses
+    term_vals = [[factor_value_and_grads(f, theta, X) for f in term] for term in spec["terms"]]
+    Ky = np.zeros((N, N))
+    for vals in term_vals:
+        prod = vals[0][0] if len(vals) == 1 else np.prod([k for k, _ in vals], axis=0)
+        Ky += prod
     Ky[np.diag_indices(N)] += theta[spec["noise"]]
     L = np.linalg.cholesky(Ky)
     r = _resid(spec, theta, y)
     z = scipy.linalg.solve_triangular(L, r, lower=True)
     alpha = scipy.linalg.solve_triangular(L, z, lower=True, trans="T")
-    Kinv = scipy.linalg.cho_solve((L, True), np.eye(N))
+    Kinv, info = scipy.linalg.lapack.dpotri(L, lower=1)
+    if info != 0:
+        raise np.linalg.LinAlgError("dpotri failed")
+    Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
     W = np.outer(alpha, alpha) - Kinv
     val = float(-0.5 * z @ z - np.sum(np.log(np.diag(L))) - 0.5 * N * LOG_2PI)
     g = np.zeros(len(spec["params"]))
-    for pi, dK in gram_param_grads(spec, theta, X).items():
-        g[pi] += 0.5 * np.sum(W * dK)
+    for term, vals in zip(spec["terms"], term_vals):
+        for gi, f in enumerate(term):
+            Wo = W
+            for fi, (k, _) in enumerate(vals):
+                if fi != gi:
+                    Wo = Wo * k
+            for pi, dk in zip(f["p"], vals[gi][1]):
+                g[pi] += 0.5 * float(np.vdot(Wo, dk))
     g[spec["noise"]] += 0.5 * np.trace(W)
     if spec.get("mean") is not None:
         g[spec["mean"]] += np.sum(alpha)

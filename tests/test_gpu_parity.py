@@ -704,7 +704,8 @@ def test_multi_structure_fit_with_priors_and_a_failing_task(ctx):
     prob = Problem(ctx, X, Y, specs, max_batch=4)
     r = prob.fit_multi(cols, sidx, U0, opts, prior_scale=scale)
     prob.close()
-    assert not np.isfinite(r["loss"][2]) or r["status"][2] != 0
+    from waveome_amd import _lib as L
+    assert r["loss"][2] == np.inf and r["lml"][2] == -np.inf and r["status"][2] == L.LB_ABNORMAL
     good = [0, 1, 3]
     assert np.all(np.isfinite(r["loss"][good]))
     for t in good:  # each good task equals the same task fitted alone

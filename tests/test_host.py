@@ -149,6 +149,11 @@ def test_lbfgs_limits_and_nonfinite(lib):
         return rosen(x), rosen_der(x)
     m = _run_mine(lib, walled, np.full(4, -1.2), maxiter=500)
     assert m["task"] in (_lib.LB_CONV_FTOL, _lib.LB_CONV_GTOL) and m["f"] < 1e-6
+    # a fit whose very first evaluation is non-finite ends ABNORMAL and must not report a finite objective
+    for bad in (np.inf, np.nan):
+        m = _run_mine(lib, lambda x: (bad, np.zeros_like(x)), np.zeros(3))
+        assert m["task"] == _lib.LB_ABNORMAL and m["nit"] == 0 and m["nfev"] == 1
+        assert m["f"] == np.inf
 
 
 # ---------------------------------------------------------------- spec helpers

@@ -163,6 +163,7 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
                             hipMemcpyDeviceToHost, st));
   WV_HIP_TRY(hipEventRecord(g.done, st));
   WV_HIP_TRY(hipGetLastError());
+  if (take_launch_failure()) return WV_E_UNSUPPORTED;  // message already set by the launcher
   return WV_OK;
 }
 
@@ -678,14 +679,19 @@ static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* sp
       if (task != WV_LB_FG) {
         const int t = s.task;
         std::memcpy(theta_u_inout + (size_t)t * u_stride, s.opt->x(), sizeof(double) * sp.n_trainable());
-        if (loss_out) loss_out[t] = s.opt->f();
+        // a fit that never saw a finite evaluation (NaN in the column, K_y not positive definite at the
+        // start point) reports loss = +inf, lml = -inf and WV_LB_ABNORMAL - never a finite score
+        const double f_end = s.opt->f();
+        const bool f_ok = std::isfinite(f_end);
+        if (loss_out) loss_out[t] = f_ok ? f_end : std::numeric_limits<double>::infinity();
         if (n_iter_out) n_iter_out[t] = s.opt->n_iter();
         if (n_eval_out) n_eval_out[t] = s.opt->n_eval();
-        if (status_out) status_out[t] = task;
+        if (status_out) status_out[t] = f_ok ? task : WV_LB_ABNORMAL;
         if (lml_out) {
           // LML at the returned point = -(loss) - log prior
           sp.constrain(s.opt->x(), theta.data());
-          lml_out[t] = -s.opt->f() - sp.log_prior(theta.data(), nullptr, ps);
+          lml_out[t] = f_ok ? -f_end - sp.log_prior(theta.data(), nullptr, ps)
+                            : -std::numeric_limits<double>::infinity();
         }
         s.task = -1;
         ++finished;

@@ -125,6 +125,7 @@ static int32_t dbg_gemm_impl(wv_ctx* ctx, const double* A, const double* B, doub
   g.lda = a_kc ? K : M; g.ldb = b_kc ? K : N; g.ldc = N;
   g.M = M; g.N = N; g.kb = 0; g.ke = K; g.alpha = alpha; g.beta = beta; g.nbatch = nbatch;
   launch_gemm(nullptr, g, a_kc != 0, b_kc != 0, bn);
+  if (take_launch_failure()) return WV_E_UNSUPPORTED;
   WV_HIP_TRY(hipGetLastError());
   WV_HIP_TRY(hipDeviceSynchronize());
   WV_HIP_TRY(hipMemcpy(hC.data(), dC, sizeof(R) * nc, hipMemcpyDeviceToHost));

@@ -308,6 +308,12 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + bn - 1) / bn;
   if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
+  // the kernel walks the contraction in chunks of KC = 16 from 16-aligned offsets (Npad is a multiple of 64, so
+  // every schedule in wv_chol.hip satisfies this); anything else would silently drop a remainder
+  if ((a.ke - a.kb) % KC != 0 || a.kb % KC != 0 || a.koff % KC != 0) {
+    fail_launch("launch_gemm: contraction range / offset not a multiple of 16");
+    return;
+  }
   int tiles = a.tiles_m * a.tiles_n;
   if (a.tri) {
     tiles = 0;
@@ -346,8 +352,7 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
       if (bn == 128) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 2>), g, blk, 0, st, a);
       else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 64, 2, 2>), g, blk, 0, st, a);
     } else {
-      fprintf(stderr, "launch_gemm: unsupported transposed-output variant\n");
-      abort();
+      fail_launch("launch_gemm: unsupported transposed-output variant");
     }
     return;
   }

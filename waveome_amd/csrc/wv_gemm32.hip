@@ -252,8 +252,8 @@ void launch_gemm(hipStream_t st, const GemmArgsF& a_in, bool a_kc, bool b_kc, in
   using namespace g32;
   GemmArgsF a = a_in;
   if (b_kc) {
-    fprintf(stderr, "launch_gemm(float32): K-contiguous B is not used by the schedule and not built\n");
-    abort();
+    fail_launch("launch_gemm(float32): K-contiguous B is not used by the schedule and not built");
+    return;
   }
   if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -280,8 +280,7 @@ void launch_gemm(hipStream_t st, const GemmArgsF& a_in, bool a_kc, bool b_kc, in
   } else if (a.tout == 2 && !a_kc) {
     hipLaunchKernelGGL((gemm_f32_kernel<false, 2>), g, blk, 0, st, a);
   } else {
-    fprintf(stderr, "launch_gemm(float32): unsupported transposed-output variant\n");
-    abort();
+    fail_launch("launch_gemm(float32): unsupported transposed-output variant");
   }
 }
 

@@ -20,6 +20,7 @@
 // whole minimise, waveome/model_classes.py:323-340).
 #pragma once
 #include <cstdint>
+#include <limits>
 #include <vector>
 
 #include "../../include/waveome_amd.h"
@@ -61,7 +62,8 @@ class Lbfgs {
   std::vector<double> S_, Y_, rho_;  // ring buffers, m x n
   int col_ = 0, head_ = 0;           // number of stored pairs, index of the oldest
   double theta_ = 1.0;
-  double f_ = 0, fold_ = 0, gd_ = 0, gdold_ = 0, stp_ = 0, dnorm_ = 0, sbgnrm_ = 0;
+  // f_ starts at +inf: a fit whose very first evaluation is non-finite must not report a finite loss
+  double f_ = std::numeric_limits<double>::infinity(), fold_ = 0, gd_ = 0, gdold_ = 0, stp_ = 0, dnorm_ = 0, sbgnrm_ = 0;
   int iter_ = 0, nfev_ = 0, ifun_ = 0, iback_ = 0;
   bool first_ = true, in_ls_ = false;
   double bis_lo_ = 0;  // non-finite handling: last finite step on the ray

@@ -9,6 +9,11 @@ namespace wv {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+// A launcher that cannot serve a request (an argument combination no kernel instantiation covers) records it
+// here instead of aborting the host process; the C-ABI entry point that enqueued it reports WV_E_UNSUPPORTED.
+static thread_local bool g_launch_failed = false;
+void fail_launch(const std::string& msg) { g_err = msg; g_launch_failed = true; }
+bool take_launch_failure() { bool f = g_launch_failed; g_launch_failed = false; return f; }
 
 int n_factor_params(int type) {
   switch (type) {

@@ -42,5 +42,7 @@ double sigmoid(double u);
 double horseshoe_logpdf(double x, double scale, double* dlogp);
 
 void set_error(const std::string& msg);
+void fail_launch(const std::string& msg);
+bool take_launch_failure();
 
 }  // namespace wv
