@@ -7,6 +7,10 @@ literals; expected values are the numbers printed in the stored cell outputs:
 * KAT-1  kernel_learning/gpflow_basic_colab.ipynb cells 3,4,6,7
 * KAT-2  kernel_learning/gpflow_basic.ipynb cells 28-31
 * KAT-3  kernel_learning/gpflow_basic_colab.ipynb cell 7 (comment "M12 = -10.68")
+* KAT-4  waveome_overview.ipynb cells 4, 8, 9, 10, 11, 13: the end-to-end penalised run
+         (GPSearch(...).penalized_optimization(random_seed=9102, kerns=[SE, Lin()])) on 100 people x 5
+         observations; stored: the first rows of the data frame (checked below), the fitted `outcome1`
+         model table, its surviving component, the "245 log Bayes factor / ~2 % residual" of cell 10
 
 Run:  python tests/golden/make_kat.py
 """
@@ -48,6 +52,55 @@ out = {
         "expected": {"lml_2dp": -10.68},
     },
 }
+# ---- KAT-4: waveome_overview.ipynb cell 4, statement for statement (legacy NumPy RNG; note the sort) ----
+import pandas as pd
+
+n_people, n_observations = 100, 5
+total_obs = n_people * n_observations
+np.random.seed(9102)
+id_vec = np.repeat(np.arange(n_people), repeats=n_observations)
+time_vec = np.random.uniform(low=0, high=12, size=total_obs)
+female_vec = np.repeat(np.random.choice(a=["N", "Y"], size=n_people), repeats=n_observations)
+out1_vec = np.sin(time_vec)
+out2_vec = (female_vec == "Y") * np.cos(time_vec)
+out3_vec = 0.5 * time_vec + np.repeat(np.random.normal(scale=1.0, size=n_people), repeats=n_observations)
+out1_vec += np.random.normal(scale=0.1, size=total_obs)
+out2_vec += np.random.normal(scale=0.1, size=total_obs)
+out3_vec += np.random.normal(scale=0.1, size=total_obs)
+df = pd.DataFrame({"person_id": id_vec, "time": time_vec, "female": female_vec, "outcome1": out1_vec,
+                   "outcome2": out2_vec, "outcome3": out3_vec}).sort_values(["person_id", "time"])
+# the notebook's stored df.head() (cell 4 output) pins the regeneration
+head = [(0, 1.175864, "Y", 0.889715, 0.381912, 1.314904), (0, 1.843311, "Y", 1.031439, -0.305892, 1.545721),
+        (0, 5.038792, "Y", -1.266127, 0.171152, 3.201142), (0, 5.982431, "Y", -0.373667, 1.011684, 3.873555),
+        (0, 11.815789, "Y", -0.751300, 0.657616, 6.397673)]
+for row, want in zip(df.head().itertuples(index=False), head):
+    assert row[0] == want[0] and row[2] == want[2]
+    assert all(abs(a - b) < 5e-7 for a, b in zip((row[1],) + tuple(row[3:]), (want[1],) + want[3:])), (row, want)
+
+out["kat4"] = {
+    "source": "waveome_overview.ipynb cells 4 (data), 8-9 (call), 10-11, 13 (stored results)",
+    "call": "GPSearch(X=df[[person_id, time, female]], Y=df[[outcome1..3]], unit_col='person_id', "
+            "categorical_vars=['female']).penalized_optimization(random_seed=9102, kernel_options={"
+            "second_order_numeric: False, unit_numeric_interactions: False, categorical_numeric_interactions: True, "
+            "kerns: [SquaredExponential(), Lin()]})",
+    "columns": {"person_id": df["person_id"].tolist(), "time": df["time"].tolist(),
+                "female": df["female"].tolist(), "outcome1": df["outcome1"].tolist(),
+                "outcome2": df["outcome2"].tolist(), "outcome3": df["outcome3"].tolist()},
+    "expected": {
+        # cell 11: print_summary of gps.models["outcome1"] (the parameters of the full penalised fit; pruning
+        # happens after the fit and nothing is re-optimised, model_search.py:376-387)
+        "outcome1": {"kernel_name": "squared_exponential[time]", "mean_function.c": -0.00926197,
+                     "kernel.variance": 1.31726, "kernel.lengthscales": 0.6039889078720436,
+                     "likelihood.variance": 0.010671648921161738,
+                     "Z_row0": [0.0, -1.44041, 0.0],         # factorised ids, ddof=1 standardised time, female 'Y' -> 0
+                     "q_mu_0": 8.19377189e-01, "q_sqrt_00": 1.51608043e-02,
+                     "log_bayes_factor": 245.0, "residual_share": 0.02},   # cell 10 text
+        # cell 13 text
+        "outcome2": {"first_component_involves": ["female", "time"]},
+        "outcome3": {"has_component": "person_id"},
+    },
+}
+
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat.json")
 with open(path, "w") as fh:
     json.dump(out, fh, indent=1)

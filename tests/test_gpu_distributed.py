@@ -18,9 +18,20 @@ import os, pickle, sys
 import numpy as np, pandas as pd
 sys.path.insert(0, os.environ["WV_ROOT"])
 world = int(os.environ.get("WORLD_SIZE", "1"))
-if world > 1:
+backend = os.environ.get("WV_BACKEND")
+if backend:
+    import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
+    from waveome_amd import parallel
+    from waveome_amd.model_classes import default_context
+    assert parallel.dist_active() and parallel.dist_backend() == backend
+    # one process per GPU: the default context sits on LOCAL_RANK modulo the visible devices
+    assert default_context().device == int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    # collectives move device memory under nccl (RCCL), host memory under gloo
+    assert parallel.collective_device().type == ("cuda" if backend == "nccl" else "cpu")
 from waveome_amd import kernels as K
 from waveome_amd.model_search import GPSearch
 rng = np.random.default_rng(3)
@@ -40,7 +51,9 @@ out["search"] = {f: {n_: m["bic"] for n_, m in gps.search_info[f]["models"].item
 out["best"] = {f: gps.search_info[f]["best_model"] for f in gps.out_names}
 with open(os.environ["WV_OUT"] + "." + os.environ.get("RANK", "s"), "wb") as fh:
     pickle.dump(out, fh)
-if world > 1:
+if backend:
+    sh = parallel.broadcast_inputs(X.to_numpy(float), Y.to_numpy(float))
+    out["shared_on_device"] = bool(sh._Xt is not None and sh._Xt.is_cuda)
     dist.barrier()
     dist.destroy_process_group()
 '''
@@ -65,8 +78,8 @@ def test_two_ranks_reproduce_the_single_process_results(tmp_path):
     log, _ = p.communicate(timeout=600)
     assert p.returncode == 0, log.decode()[-3000:]
     port = _free_port()
-    procs = [_run({"RANK": str(r), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, out)
-             for r in range(2)]
+    procs = [_run({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                   "MASTER_PORT": str(port), "WV_BACKEND": "gloo"}, out) for r in range(2)]
     for q in procs:
         log, _ = q.communicate(timeout=600)
         assert q.returncode == 0, log.decode()[-3000:]
@@ -76,3 +89,23 @@ def test_two_ranks_reproduce_the_single_process_results(tmp_path):
         assert got["pen"] == single["pen"]
         np.testing.assert_array_equal(got["sweep"], single["sweep"])
         assert got["search"] == single["search"] and got["best"] == single["best"]
+
+
+def test_one_rank_over_rccl_reproduces_the_single_process_results(tmp_path):
+    """backend "nccl" (= RCCL) at world size 1 - all the 1-GPU box allows: X / Y are broadcast as device tensors,
+    the problems are created from those device buffers, the records are all-gathered on the GPU; results must
+    equal the plain single-process run bit for bit."""
+    out = str(tmp_path / "res")
+    p = _run({}, out)
+    log, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, log.decode()[-3000:]
+    q = _run({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+              "MASTER_PORT": str(_free_port()), "WV_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, out)
+    log, _ = q.communicate(timeout=600)
+    assert q.returncode == 0, log.decode()[-3000:]
+    single = pickle.load(open(out + ".s", "rb"))
+    got = pickle.load(open(out + ".0", "rb"))
+    assert got["shared_on_device"] is True
+    assert got["pen"] == single["pen"]
+    np.testing.assert_array_equal(got["sweep"], single["sweep"])
+    assert got["search"] == single["search"] and got["best"] == single["best"]

@@ -32,6 +32,14 @@ np.save(os.environ["WV_OUT"] + f".ids{rank}.npy", mine)
 # fewer tasks than ranks (a search step with a single candidate): the idle rank still joins the gather
 one = parallel.sharded_map(1, fn, width=3)
 np.save(os.environ["WV_OUT"] + f".one{rank}.npy", one)
+# GPSearch-level plumbing: device of a rank, where collectives live, and rank 0's inputs on every rank
+assert parallel.dist_active() and parallel.dist_backend() == "gloo"
+assert parallel.collective_device().type == "cpu"
+assert parallel.local_device_index(8) == rank and parallel.local_device_index(1) == 0
+assert parallel.local_device_index(4, env={"LOCAL_RANK": "6"}) == 2
+mineX = np.full((40, 3), float(rank)); mineY = np.full((40, 11), float(rank))
+sh = parallel.broadcast_inputs(mineX, mineY)      # rank 1's own values must be replaced by rank 0's
+assert sh.X.shape == (40, 3) and sh.Y.shape == (40, 11) and np.all(sh.X == 0.0) and np.all(sh.Y == 0.0)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -56,12 +64,24 @@ def test_shard_tasks_is_a_balanced_partition():
     assert shard_tasks(5, 0, 1).tolist() == [0, 1, 2, 3, 4]
 
 
+def test_no_process_group_means_device_zero_and_plain_arrays():
+    from waveome_amd import parallel
+
+    assert not parallel.dist_active() and parallel.dist_backend() is None
+    assert parallel.local_device_index(8, env={"LOCAL_RANK": "3"}) == 0
+    X, Y = np.arange(6.0).reshape(3, 2), np.arange(3.0).reshape(3, 1)
+    sh = parallel.broadcast_inputs(X, Y)
+    np.testing.assert_array_equal(sh.X, X)
+    np.testing.assert_array_equal(sh.Y, Y)
+    assert sh._Xt is None
+
+
 def test_world_size_two_gloo_matches_single_process(tmp_path):
     port = _free_port()
     out = str(tmp_path / "rec")
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    WV_ROOT=ROOT, WV_OUT=out, OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))

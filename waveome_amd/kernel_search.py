@@ -303,12 +303,14 @@ class GpuScorer:
     number of trainable Parameter objects (q_mu and q_sqrt of the reference's SVGP included, hence + 2)."""
 
     def __init__(self, X, Y, context=None, max_batch=None, num_opt_iter=50000, workers=None, mode=None,
-                 num_restart=1, random_seed=None):
+                 num_restart=1, random_seed=None, shared=None):
         from .engine import lbfgs_opts
         from .model_classes import default_context
 
-        self.X = np.ascontiguousarray(X, dtype=np.float64)
-        self.Y = np.ascontiguousarray(Y, dtype=np.float64)
+        # `shared`: the inputs as parallel.broadcast_inputs left them (device tensors of the RCCL broadcast under
+        # nccl); otherwise the arrays are broadcast here so that every rank scores on rank 0's data
+        self.shared = shared if shared is not None else parallel.broadcast_inputs(X, Y)
+        self.X, self.Y = self.shared.X, self.shared.Y
         self.ctx = context or default_context()
         self.max_batch = max_batch
         self.num_restart, self.random_seed = max(1, int(num_restart)), random_seed
@@ -373,7 +375,7 @@ class GpuScorer:
                         pts = restart_points(sp.n_trainable, R, random_seed=self.random_seed)
                         U0[rows, :sp.n_trainable] = np.tile(pts, (len(rows) // R, 1))
                 mb = self.max_batch or min(len(rep), _default_batch(N))
-                prob = Problem(self.ctx, self.X, self.Y, sp_list, max_batch=max(1, mb))
+                prob = self.shared.problem(self.ctx, sp_list, max(1, mb))
                 try:
                     res = prob.fit_multi(cols_r, sidx_r, U0, self.opts)
                 finally:
@@ -392,7 +394,7 @@ class GpuScorer:
                 sp = specs[mine[rows[0]]]
                 cols = np.array([tasks[mine[r]][0] for r in rows], dtype=np.int32)
                 mb = self.max_batch or min(len(rows), _default_batch(N))
-                prob = Problem(self.ctx, self.X, self.Y, sp, max_batch=max(1, mb))
+                prob = self.shared.problem(self.ctx, sp, max(1, mb))
                 try:
                     res = prob.fit(cols, np.tile(sp.unconstrain(), (len(rows), 1)), self.opts)
                 finally:
@@ -416,7 +418,7 @@ class GpuScorer:
 
         if order:
             rank, world = parallel.dist_info()
-            rec = parallel.sharded_map(len(order), fit_shard, costs=costs, width=5 + width) if world > 1 \
+            rec = parallel.sharded_map(len(order), fit_shard, costs=costs, width=5 + width) if parallel.dist_active() \
                 else fit_shard(np.arange(len(order)))
             self.n_fits += len(order)
             self.n_structures += len(groups)

@@ -25,10 +25,21 @@ from .utilities import (_gaussian_logdensity, restart_points, calc_bic, calc_fea
 _default_ctx: Optional[Context] = None
 
 
-def default_context(device: int = 0) -> Context:
+def default_context(device: Optional[int] = None) -> Context:
+    """The context API calls use when none is passed: GPU 0, or under torch.distributed (one process per GPU) the
+    GPU of this rank - LOCAL_RANK modulo the visible devices."""
+    from . import _lib, parallel
     from .utilities import get_precision
 
     global _default_ctx
+    if device is None:
+        device = 0
+        if parallel.dist_active():
+            import ctypes
+
+            n = ctypes.c_int32(0)
+            _lib.load().wv_device_count(ctypes.byref(n))
+            device = parallel.local_device_index(n.value)
     if _default_ctx is None or _default_ctx.device != device or _default_ctx.dtype != get_precision():
         _default_ctx = Context(device, dtype=get_precision())
     return _default_ctx
@@ -151,15 +162,33 @@ class PSVGP:
             prob.close()
 
     def optimize_params(self, optimizer="scipy", data=None, num_opt_iter=50000, **_ignored):
-        """L-BFGS-B on -(LML + log prior) (reference: model_classes.py:299-342, scipy branch)."""
+        """L-BFGS-B on -(LML + log prior) (reference: model_classes.py:299-342, scipy branch).  A fit that fails
+        at its start point (no finite evaluation: K_y not positive definite there) is retried from randomised
+        parameters, up to 5 times, as the reference's except-branch does (:323-340); if every attempt fails the
+        parameters are left as they were and a warning names the outcome."""
         if optimizer not in ("scipy", None):
             raise NotImplementedError("only optimizer='scipy' (L-BFGS-B) is implemented on the GPU path")
         self.optimizer = "scipy"
         spec, prob = self._problem()
-        res = prob.fit([self._col], spec.unconstrain()[None, :], lbfgs_opts(maxiter=num_opt_iter))
-        spec.assign_theta(spec.constrain(res["u"][0]))
+        opts = lbfgs_opts(maxiter=num_opt_iter)
+        start = spec.unconstrain()[None, :]
+        try:
+            res = prob.fit([self._col], start, opts)
+            attempt = 0
+            while not np.isfinite(res["loss"][0]) and attempt < 5:
+                attempt += 1
+                res = prob.fit([self._col], restart_points(spec.n_trainable, attempt)[-1:], opts)
+        finally:
+            self._release(prob)
         self.fit_result = {k: v[0] for k, v in res.items()}
-        self._release(prob)
+        if np.isfinite(res["loss"][0]):
+            spec.assign_theta(spec.constrain(res["u"][0]))
+        else:
+            import warnings
+
+            warnings.warn("optimize_params: no finite objective value from the start point or 5 randomised "
+                          "restarts; parameters left unchanged (status "
+                          f"{int(res['status'][0])})")
         return None
 
     def maximum_log_likelihood_objective(self, data=None):
@@ -313,21 +342,21 @@ class PSVGP:
                 tspec.assign_theta(tspec.constrain(u))
                 holdout = np.mean(twin.predict_log_density((X[fold], Y[fold])))
                 results.append([pf, h, holdout])
-        parallel_results = np.array(results)
-        self.penalization_search_results = parallel_results
-        max_val, max_factor = -np.inf, -np.inf
-        for factor in factors:
-            vals = parallel_results[parallel_results[:, 0] == factor, 2]
-            cur_val = vals.mean()
-            if selection_type == "se":
-                cur_val -= vals.std() / np.sqrt(k_fold)
-            if cur_val > max_val:
-                max_factor, max_val = factor, cur_val
-        best_factor = max_factor
-        if max_factor == -np.inf:
+        table = np.array(results)  # rows (factor, fold, mean holdout log-density)
+        self.penalization_search_results = table
+        # per factor: mean over folds, minus one standard error for selection_type "se"; the first factor with the
+        # strictly highest score wins; a search without a finite score falls back to no penalisation (:959-996)
+        by_factor = np.array([table[table[:, 0] == f, 2] for f in factors])
+        score = by_factor.mean(axis=1)
+        if selection_type == "se":
+            score = score - by_factor.std(axis=1) / np.sqrt(k_fold)
+        score = np.where(np.isnan(score), -np.inf, score)
+        if np.all(np.isneginf(score)):
             if self.verbose:
                 print("Search error, returning no penalization")
             best_factor = 0.0
+        else:
+            best_factor = factors[int(np.argmax(score))]
         if self.verbose:
             print(f"Best penalization factor found from search: {best_factor}")
         if fit_best:
@@ -372,20 +401,19 @@ class PSVGP:
                         k=len(self.trainable_parameters) + 2)
 
     def cut_kernel_components(self, data=None, var_cutoff: float = 0.1):
-        """Drop additive terms with variance < var_cutoff, then factors whose lengthscale is
-        >= 3 x the input range (model_classes.py:1029-1079)."""
-        var_parts = find_variance_components(self.kernel, sum_reduce=False)
-        var_parts = np.asarray(var_parts).reshape(-1)
-        var_flag = np.where(var_parts >= var_cutoff)[0]
-        if len(var_flag) > 1:
-            self.kernel = K.Sum([self.kernel.kernels[i] for i in var_flag])
-        elif len(var_flag) == 1:
-            if len(var_parts) > 1:
-                self.kernel = self.kernel.kernels[var_flag[0]]
-        else:
+        """Post-fit pruning (model_classes.py:1029-1079): additive components whose variance (a product's: the
+        product of its factors') is below `var_cutoff` are dropped - none left makes the kernel a Constant(), one
+        left stands alone - and what remains of a Sum / Product is passed through the lengthscale rule
+        (`search_through_kernel_list_`: lengthscale >= 3 x the input range goes)."""
+        components = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
+        strength = np.asarray(find_variance_components(self.kernel, sum_reduce=False), dtype=np.float64).reshape(-1)
+        kept = [c for c, v in zip(components, strength) if v >= var_cutoff]
+        if not kept:
             self.kernel = K.Constant()
+        elif self.kernel.name == "sum":
+            self.kernel = kept[0] if len(kept) == 1 else K.Sum(kept)
         if hasattr(self.kernel, "kernels"):
             X = self.data[0] if data is None else np.asarray(data[0])
-            self.kernel = search_through_kernel_list_(kernel_list=self.kernel.kernels,
-                                                      list_type=self.kernel.name, X=X)
+            self.kernel = search_through_kernel_list_(kernel_list=self.kernel.kernels, list_type=self.kernel.name,
+                                                      X=X)
         return None

@@ -28,59 +28,67 @@ class GPSearch:
 
     def __init__(self, X, Y, unit_col=None, standardize_X=True, Y_transform=None, categorical_vars=[],
                  outcome_likelihood="gaussian"):
-        if not isinstance(X, pd.DataFrame):
-            raise TypeError("X is not a Pandas DataFrame")
-        if not isinstance(Y, pd.DataFrame):
-            raise TypeError("Y is not a Pandas DataFrame")
-        X = X.copy()
-        categorical_vars = list(categorical_vars)  # the reference mutates its default argument
-        if unit_col is not None and unit_col not in categorical_vars:
-            categorical_vars += [unit_col]
-        self.categorical_dict = {}
-        for c in categorical_vars:
-            if X[c].dtype in ["object", "string"] or str(X[c].dtype) in ("object", "string", "category", "str"):
-                print(f"Converting {c} to numeric")
-                factor_out = pd.factorize(X[c])
-                self.categorical_dict[c] = factor_out
-                X[c] = factor_out[0].astype(float)
-        try:
-            X = X.astype(float)
-        except Exception:
-            raise TypeError("X columns must all be float type. Perhaps use pandas.factorize() and"
-                            " pandas.DataFrame.astype().")
-        try:
-            Y = Y.astype(float)
-        except Exception:
-            raise TypeError("Y columns must all be float type. Perhaps use pandas.factorize() and"
-                            " pandas.DataFrame.astype().")
-        assert X.isna().sum().sum() == 0, "NAs in X, waveome cannot currently handle missing values!"
-        assert Y.isna().sum().sum() == 0, "NAs in Y, waveome cannot currently handle missing values!"
-        self.X = X.copy()
-        self.Y = Y.copy()
-        self.feat_names = X.columns.tolist()
-        self.out_names = Y.columns.tolist()
-        self.cat_idx = [self.feat_names.index(x) for x in categorical_vars]
-        self.unit_idx = self.feat_names.index(unit_col) if unit_col is not None else None
+        for frame, label in ((X, "X"), (Y, "Y")):
+            if not isinstance(frame, pd.DataFrame):
+                raise TypeError(f"{label} is not a Pandas DataFrame")
+        # the unit column is a categorical column too (the reference appends it to its mutable default list)
+        cat_names = list(categorical_vars) + ([unit_col] if unit_col is not None and unit_col not in categorical_vars
+                                              else [])
+        X, self.categorical_dict = self._encode_categoricals(X.copy(), cat_names)
+        X, Y = self._all_float(X, "X"), self._all_float(Y, "Y")
+        self.X, self.Y = X.copy(), Y.copy()
+        self.feat_names, self.out_names = list(X.columns), list(Y.columns)
         self.likelihood = outcome_likelihood
-        self.cont_idx = np.where(~np.isin(np.arange(X.shape[1]), self.cat_idx))[0].tolist()
+        self.cat_idx = [self.feat_names.index(name) for name in cat_names]
+        self.unit_idx = None if unit_col is None else self.feat_names.index(unit_col)
+        self.cont_idx = [i for i in range(X.shape[1]) if i not in set(self.cat_idx)]
         if standardize_X:
-            self.X_means = self.X.iloc[:, self.cont_idx].mean(axis=0)
-            self.X_stds = self.X.iloc[:, self.cont_idx].std(axis=0)  # pandas: ddof = 1
-            self.X_original = self.X.copy()
-            for c in self.cont_idx:
-                name = self.feat_names[c]
-                self.X[name] = (self.X[name] - self.X_means[name]) / self.X_stds[name]
-        if Y_transform == "standardize":
-            if self.likelihood != "gaussian":
-                warnings.warn("Standardizing Y without a gaussian likelihood is not advised!")
+            self._standardize_continuous()
+        self._transform_outputs(Y_transform)
+
+    @staticmethod
+    def _encode_categoricals(X, cat_names):
+        """Text-like categorical columns become float codes in order of first appearance (pd.factorize); the
+        (codes, uniques) pair is kept per column for decoding (model_search.py:98-104)."""
+        encodings = {}
+        for name in cat_names:
+            if str(X[name].dtype) in ("object", "string", "category", "str"):
+                print(f"Converting {name} to numeric")
+                encodings[name] = pd.factorize(X[name])
+                X[name] = encodings[name][0].astype(float)
+        return X, encodings
+
+    @staticmethod
+    def _all_float(frame, label):
+        """Cast to float, refuse missing values (model_search.py:106-140)."""
+        try:
+            frame = frame.astype(float)
+        except Exception:
+            raise TypeError(f"{label} columns must all be float type. Perhaps use pandas.factorize() and"
+                            " pandas.DataFrame.astype().")
+        assert frame.isna().sum().sum() == 0, f"NAs in {label}, waveome cannot currently handle missing values!"
+        return frame
+
+    def _standardize_continuous(self):
+        """Continuous columns to zero mean / unit sample standard deviation (pandas .std(): ddof = 1), categorical
+        codes untouched; the originals and the moments are kept (model_search.py:155-168)."""
+        cont = [self.feat_names[i] for i in self.cont_idx]
+        self.X_original = self.X.copy()
+        self.X_means, self.X_stds = self.X[cont].mean(axis=0), self.X[cont].std(axis=0)
+        self.X[cont] = (self.X[cont] - self.X_means) / self.X_stds
+
+    def _transform_outputs(self, how):
+        """Y_transform: "standardize" (centre and scale) or "scale" (scale only) (model_search.py:172-191)."""
+        if how not in ("standardize", "scale"):
+            return
+        if how == "standardize" and self.likelihood != "gaussian":
+            warnings.warn("Standardizing Y without a gaussian likelihood is not advised!")
+        self.Y_original = self.Y.copy()
+        self.Y_stds = self.Y.std(axis=0)
+        if how == "standardize":
             self.Y_means = self.Y.mean(axis=0)
-            self.Y_stds = self.Y.std(axis=0)
-            self.Y_original = self.Y.copy()
-            self.Y = (self.Y - self.Y_means) / self.Y_stds
-        elif Y_transform == "scale":
-            self.Y_stds = self.Y.std(axis=0)
-            self.Y_original = self.Y.copy()
-            self.Y = self.Y / self.Y_stds
+            self.Y = self.Y - self.Y_means
+        self.Y = self.Y / self.Y_stds
 
     # ------------------------------------------------------------------------------------------
     def penalized_optimization(self, full_kernel=None, num_jobs=-1, verbose=False, mean_function=None,
@@ -122,8 +130,9 @@ class GPSearch:
             full_kernel = copy.deepcopy(full_kernel)
         variational_options = dict(variational_options, likelihood=self.likelihood)
 
-        Xn = self.X.to_numpy(dtype=np.float64)
-        Yn = self.Y.to_numpy(dtype=np.float64)
+        # rank 0's X and Y go out to every rank (RCCL broadcast under nccl; the reference's ray.put, :434-472)
+        shared = parallel.broadcast_inputs(self.X.to_numpy(dtype=np.float64), self.Y.to_numpy(dtype=np.float64))
+        Xn, Yn = shared.X, shared.Y
         P = Yn.shape[1]
         # penalization_factor=None: analytic factor 2 * 1.1 * sigma_hat * sqrt(N) * Phi^-1(1 - 0.1 / (2 p)) per
         # output, then up to num_factor_iter re-fits with sigma_hat = sqrt(mean predict_y variance)
@@ -171,7 +180,7 @@ class GPSearch:
 
         def fit_shard(ids):
             mb = max_batch or min(len(ids), _default_batch(len(Xn)))
-            prob = Problem(ctx, Xn, Yn, spec, max_batch=max(1, mb))
+            prob = shared.problem(ctx, spec, max(1, mb))
             scale = (1.0 / pf[cols[ids]]) if has_prior else None
             res = prob.fit(cols[ids], starts[ids], opts, prior_scale=scale)
             u, pf_used = res["u"], pf[cols[ids]].copy()
@@ -207,7 +216,8 @@ class GPSearch:
             return np.column_stack([res["loss"], res["lml"], res["nit"] + extra[:, 0], res["nfev"] + extra[:, 1],
                                     res["status"], pf_used, u])
 
-        rec = parallel.sharded_map(len(cols), fit_shard) if world > 1 else fit_shard(np.arange(len(cols)))
+        rec = parallel.sharded_map(len(cols), fit_shard, width=6 + nt) if parallel.dist_active() \
+            else fit_shard(np.arange(len(cols)))
         self.fit_records = rec
         self.models = {}
         pool = ProblemPool(float64_context(ctx), Xn, Yn)  # post-fit steps of outputs with the same pruned structure share a problem
@@ -215,6 +225,11 @@ class GPSearch:
             block = rec[p * n_starts:(p + 1) * n_starts]
             # restarts: keep the highest maximum_log_likelihood_objective (model_classes.py:511-519)
             best = block[np.argmax(np.where(np.isfinite(block[:, 1]), block[:, 1], -np.inf))]
+            if not np.isfinite(best[0]):  # the reference's task would have raised after its retries (:323-340)
+                warnings.warn(f"penalized_optimization: no finite objective value for output {feat!r} "
+                              f"(status {int(best[4])}); its model keeps the default parameter values")
+                best = best.copy()
+                best[6:6 + nt] = u0
             mod = PSVGP(Xn, Yn[:, p:p + 1], mean_function=mean_function, kernel=full_kernel, verbose=verbose,
                         penalized_options={"penalization_factor": float(best[5])},
                         variational_options=variational_options, context=context)
@@ -258,8 +273,8 @@ class GPSearch:
         names = list(kernels)
         if mean_function is None:
             mean_function = K.ConstantMean()
-        Xn = self.X.to_numpy(dtype=np.float64)
-        Yn = self.Y.to_numpy(dtype=np.float64)
+        shared = parallel.broadcast_inputs(self.X.to_numpy(dtype=np.float64), self.Y.to_numpy(dtype=np.float64))
+        Xn, Yn = shared.X, shared.Y
         N, P, S = Xn.shape[0], Yn.shape[1], len(names)
         ctx = context or default_context()
         opts = lbfgs_opts(maxiter=num_opt_iter)
@@ -296,7 +311,7 @@ class GPSearch:
                 s_ = task_s[t]
                 U0[row, :specs[s_].n_trainable] = starts[s_][t - s_ * P * n_starts]
             mb = max_batch or min(len(ids), _default_batch(N))
-            prob = Problem(ctx, Xn, Yn, [specs[s_] for s_ in used], max_batch=max(1, mb))
+            prob = shared.problem(ctx, [specs[s_] for s_ in used], max(1, mb))
             try:
                 res = prob.fit_multi(task_p[ids].astype(np.int32), sidx, U0, opts)
             finally:
@@ -307,7 +322,8 @@ class GPSearch:
 
         rank, world = parallel.dist_info()
         n_tasks = len(task_s)
-        rec = parallel.sharded_map(n_tasks, fit_shard, costs=costs) if world > 1 else fit_shard(np.arange(n_tasks))
+        rec = parallel.sharded_map(n_tasks, fit_shard, costs=costs, width=5 + width) if parallel.dist_active() \
+            else fit_shard(np.arange(n_tasks))
         rows, self.sweep_models = [], {}
         for s_, nm in enumerate(names):
             sp = specs[s_]
@@ -355,14 +371,14 @@ class GPSearch:
             kernels = [K.SquaredExponential(), K.Matern12(), K.Lin(), K.Periodic(K.SquaredExponential())]
         if random_seed is not None:
             np.random.seed(random_seed)
-        Xn = self.X.to_numpy(dtype=np.float64)
-        Yn = self.Y.to_numpy(dtype=np.float64)
+        shared = parallel.broadcast_inputs(self.X.to_numpy(dtype=np.float64), self.Y.to_numpy(dtype=np.float64))
+        Xn, Yn = shared.X, shared.Y
         P = Yn.shape[1]
         print(f"Building {len(self.out_names)} models...")
         start_time = time.time()
         if scorer is None:
             scorer = ks.GpuScorer(Xn, Yn, context=context, max_batch=max_batch, num_restart=num_restart,
-                                  random_seed=random_seed)
+                                  random_seed=random_seed, shared=shared)
         out = ks.run_searches(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
                               max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
                               early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)

@@ -4,10 +4,12 @@ Replaces the Ray fan-out of waveome/model_search.py:411-512 (one remote task per
 `ray.put` of X / Y, `ray.get` of pickled models).  One process per GPU, `torch.distributed`
 (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for the CPU tests):
 
-  1. rank 0 broadcasts X (N x D) and Y (P x N) once           -> `broadcast_array`
+  1. rank 0 broadcasts X (N x D) and Y (P x N) once           -> `broadcast_inputs` / `broadcast_array`
   2. every rank fits a static, cost-balanced shard of tasks    -> `shard_tasks`
   3. fixed-width result records are all-gathered               -> `gather_records`
 
+Collectives run on this rank's GPU under nccl (RCCL moves device memory only) and on the CPU under gloo
+(`collective_device`); the GPU of a rank is LOCAL_RANK modulo the visible devices (`local_device_index`).
 There is no data-path collective inside a fit: a single fit never spans GPUs.
 torch is imported lazily so single-GPU use never pays for it."""
 from __future__ import annotations
@@ -38,6 +40,89 @@ def dist_info():
     return 0, 1
 
 
+def dist_active() -> bool:
+    """True when a torch.distributed process group is initialised (a world of ONE rank included: its
+    collectives still run, which is how the RCCL plumbing is rehearsed on a one-GPU box)."""
+    import sys
+
+    if "torch" not in sys.modules:
+        return False
+    try:
+        dist = _dist()
+        return bool(dist.is_available() and dist.is_initialized())
+    except Exception:
+        return False
+
+
+def dist_backend() -> Optional[str]:
+    """"nccl" (= RCCL on ROCm), "gloo", ... or None when torch.distributed is not initialised."""
+    if not dist_active():
+        return None
+    return str(_dist().get_backend())
+
+
+def local_device_index(n_devices: int, env=None) -> int:
+    """The GPU ordinal of this process: LOCAL_RANK (torchrun; RANK as a fallback) modulo the visible devices, 0
+    outside torch.distributed.  One process per GPU."""
+    import os
+
+    env = os.environ if env is None else env
+    rank, world = dist_info()
+    if not dist_active():
+        return 0
+    local = env.get("LOCAL_RANK", env.get("RANK", str(rank)))
+    return int(local) % max(1, int(n_devices))
+
+
+def collective_device(device=None):
+    """Where the tensors of a collective must live: the caller's choice, else this rank's GPU under the nccl
+    backend (RCCL moves device memory only), else the CPU (gloo)."""
+    import torch
+
+    if device is not None:
+        return torch.device(device)
+    if dist_backend() == "nccl":
+        return torch.device("cuda", local_device_index(torch.cuda.device_count()))
+    return torch.device("cpu")
+
+
+class SharedInputs:
+    """Rank 0's (X, Y) on every rank: host copies for the host-side logic and, under nccl, the device tensors the
+    RCCL broadcast filled (X as N x D, Y as P x N row-major - the layout `wv_problem_create` takes), so that a
+    device problem can be created from them without another host round trip."""
+
+    def __init__(self, X, Y, Xt=None, Yt=None):
+        self.X, self.Y, self._Xt, self._Yt = X, Y, Xt, Yt
+
+    def problem(self, ctx, spec, max_batch):
+        """engine.Problem on these inputs: from the broadcast's device tensors when they live on ctx's GPU
+        (device-to-device copy inside wv_problem_create), from the host copies otherwise."""
+        from .engine import Problem
+
+        if self._Xt is not None and self._Xt.is_cuda and self._Xt.device.index == ctx.device:
+            N, D = self.X.shape
+            return Problem(ctx, None, None, spec, max_batch=max_batch, x_device_ptr=self._Xt.data_ptr(),
+                           y_device_ptr=self._Yt.data_ptr(), shape=(N, D, self.Y.shape[1]))
+        return Problem(ctx, self.X, self.Y, spec, max_batch=max_batch)
+
+
+def broadcast_inputs(X: np.ndarray, Y: np.ndarray, src: int = 0, device=None) -> SharedInputs:
+    """Step 1 of the sharded path (replaces `ray.put` of X / Y, waveome/model_search.py:434-472): broadcast rank
+    `src`'s design matrix X (N x D) and outputs Y (N x P) - over RCCL when the backend is nccl.  Every rank calls
+    it with its own copies (only their shapes matter off-source); without torch.distributed it returns them."""
+    rank, world = dist_info()
+    if not dist_active():
+        return SharedInputs(np.ascontiguousarray(X, dtype=np.float64), np.ascontiguousarray(Y, dtype=np.float64))
+    import torch
+
+    dev = collective_device(device)
+    Xt = broadcast_array(X if rank == src else None, src, dev)
+    Yt = broadcast_array(np.ascontiguousarray(np.asarray(Y, dtype=np.float64).T) if rank == src else None, src, dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return SharedInputs(Xt.cpu().numpy(), np.ascontiguousarray(Yt.cpu().numpy().T), Xt, Yt)
+
+
 def shard_tasks(n_tasks: int, rank: int, world: int, costs: Optional[Sequence[float]] = None) -> np.ndarray:
     """Indices of the tasks `rank` owns: tasks sorted by decreasing cost (stable), dealt round-robin.
     Deterministic, so every rank can reconstruct every other rank's shard."""
@@ -55,7 +140,7 @@ def broadcast_array(arr: Optional[np.ndarray], src: int = 0, device=None):
 
     dist = _dist()
     rank = dist.get_rank()
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dev = collective_device(device)
     if rank == src:
         a = np.ascontiguousarray(arr, dtype=np.float64)
         meta = torch.tensor([a.ndim] + list(a.shape) + [0] * (4 - a.ndim), dtype=torch.int64, device=dev)
@@ -79,14 +164,14 @@ def gather_records(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, devic
     if len(local_ids):  # (an empty shard arrives as [0, width]: nothing to infer)
         local = local.reshape(len(local_ids), -1)
     width = local.shape[1]
-    if world == 1:
+    if not dist_active():
         out = np.empty((n_tasks, width))
         out[np.asarray(local_ids, dtype=np.int64)] = local
         return out
     import torch
 
     dist = _dist()
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dev = collective_device(device)
     cap = (n_tasks + world - 1) // world  # largest shard
     buf = torch.full((cap, width + 1), -1.0, dtype=torch.float64, device=dev)
     if len(local_ids):

@@ -55,47 +55,46 @@ def check_if_model_exists(model_name, model_list):
 
 
 def calc_rsquare(m, data=None):
-    """R-squared share of each additive component, then the residual share (waveome/utilities.py:131-188).
+    """R-squared attributed to each additive component, then the unexplained share (waveome/utilities.py:131-188).
+    The model's R^2 = 1 - SS_res / SS_tot is split over the components by how close each component's own
+    prediction comes to the full prediction: weight_k = 1 - d_k / sum_j d_j, d_k = |full mean - mean_k|^2.
     `m.component_means(data, only=True)` supplies [full, component 0 alone, 1 alone, ...] training means."""
     X, Y = m.data if data is None else data
-    Y = np.asarray(Y, dtype=np.float64).reshape(-1, 1)
-    sse = np.sum((Y - Y.mean()) ** 2)
-    mu_all_hat, _ = m.predict_y(X)
-    total_rsq = 1 - (np.sum((Y - mu_all_hat) ** 2) / sse)
-    rsq = []
-    k = m.kernel
-    if k.name == "sum":
-        means = m.component_means(data, only=True)
-        ssr_list = [np.sum((mu_all_hat - means[1 + i].reshape(-1, 1)) ** 2) for i in range(len(k.kernels))]
-        for i in range(len(k.kernels)):
-            rsq += [np.round(total_rsq * (1 - ssr_list[i] / sum(ssr_list)), 3)]
-    else:
-        rsq += [np.round(total_rsq, 3)]
-    rsq += [np.round(1 - total_rsq, 3)]
-    return rsq
+    y = np.asarray(Y, dtype=np.float64).reshape(-1)
+    fitted = np.asarray(m.predict_y(X)[0], dtype=np.float64).reshape(-1)
+    r2 = 1.0 - np.sum(np.square(y - fitted)) / np.sum(np.square(y - y.mean()))
+    if m.kernel.name != "sum":
+        return [np.round(r2, 3), np.round(1 - r2, 3)]
+    alone = np.asarray(m.component_means(data, only=True), dtype=np.float64).reshape(-1, len(y))[1:]
+    gap = np.sum(np.square(fitted[None, :] - alone[:len(m.kernel.kernels)]), axis=1)
+    return [np.round(r2 * (1.0 - g / gap.sum()), 3) for g in gap] + [np.round(1 - r2, 3)]
 
 
 def replace_kernel_variables(k_name, col_names):
-    """Indexed kernel names -> column names: "[i]" becomes "[col_names[i]]" (waveome/utilities.py:262-278)."""
-    new_k_name = k_name
-    for i, c in enumerate(col_names):
-        new_k_name = new_k_name.replace("[" + str(i) + "]", "[" + c + "]")
-    return new_k_name
+    """Indexed kernel names -> column names: "[i]" becomes "[col_names[i]]" (waveome/utilities.py:262-278).
+    Replacements are applied in column order, one after the other, as the reference does."""
+    import functools
+
+    return functools.reduce(lambda name, ic: name.replace(f"[{ic[0]}]", f"[{ic[1]}]"), enumerate(col_names), k_name)
+
+
+def _parts(kernel):
+    """Children of a Sum / Product node, None for a base kernel."""
+    return getattr(kernel, "kernels", None)
 
 
 def print_kernel_names(kernel, with_idx=False):
-    names = []
+    """Printable structure (waveome/utilities.py:366-383): a base kernel is its name (with "[column]" when
+    with_idx), a product joins its factors with "*", a sum is the LIST of its components' names."""
     if kernel is None:
         return ""
-    if hasattr(kernel, "kernels") is False:
-        if with_idx:
-            return kernel.name + "[" + str(kernel.active_dims[0]) + "]"
-        return kernel.name
-    elif kernel.name == "sum":
-        return [print_kernel_names(x, with_idx) for x in kernel.kernels]
-    elif kernel.name == "product":
-        return "*".join([print_kernel_names(x, with_idx) for x in kernel.kernels])
-    return names
+    children = _parts(kernel)
+    if children is None:
+        return f"{kernel.name}[{kernel.active_dims[0]}]" if with_idx else kernel.name
+    labels = [print_kernel_names(child, with_idx) for child in children]
+    if kernel.name == "product":
+        return "*".join(labels)
+    return labels if kernel.name == "sum" else []
 
 
 def freeze_variance_parameters(kernel):
@@ -108,44 +107,52 @@ def freeze_variance_parameters(kernel):
         K.set_trainable(kernel.variance, False)
 
 
-def find_variance_components(kern, sum_reduce=True, penalize_factor_prod=1, return_numpy=True):
-    """Variance parameter of every additive component (product = product of its factors')."""
+def _variance_of(kern, product_scale=1.0):
+    """Signal variance a kernel (sub)tree contributes: a base kernel's `variance` (Periodic: its base kernel's,
+    Empty: 0), a product multiplies its factors', a nested sum adds its components'."""
+    if kern.name == "product":
+        return product_scale * float(np.prod([_variance_of(f) for f in kern.kernels]))
     if kern.name == "sum":
-        var_list = np.stack([find_variance_components(kern=x, sum_reduce=sum_reduce) for x in kern.kernels])
-        return np.sum(var_list) if sum_reduce else var_list
-    elif kern.name == "product":
-        return np.array([penalize_factor_prod * np.prod([find_variance_components(x, sum_reduce)
-                                                          for x in kern.kernels])])
-    elif kern.name == "periodic":
-        return np.array([kern.base_kernel.variance.numpy()])
-    elif kern.name == "empty":
-        return np.zeros(1)
-    return np.array([kern.variance.numpy()])
+        return float(sum(_variance_of(c) for c in kern.kernels))
+    if kern.name == "empty":
+        return 0.0
+    holder = kern.base_kernel if kern.name == "periodic" else kern
+    return float(holder.variance.numpy())
+
+
+def find_variance_components(kern, sum_reduce=True, penalize_factor_prod=1, return_numpy=True):
+    """Variance of every additive component (waveome/utilities.py:1012-1062).  A Sum gives one row per component
+    (shape [T, 1]) or their total with sum_reduce; anything else a length-1 array.  `penalize_factor_prod` scales
+    a top-level product only, as in the reference (its recursion does not pass it down)."""
+    if kern.name == "sum":
+        rows = np.array([[_variance_of(component)] for component in kern.kernels])
+        return rows.sum() if sum_reduce else rows
+    return np.array([_variance_of(kern, penalize_factor_prod)])
 
 
 def keep_kernel_lengthscale_(kernel_component, X):
-    """False when the lengthscale is >= 3 x the range of its input column (utilities.py:1136-1153)."""
-    if kernel_component.name == "periodic":
-        kernel_component = kernel_component.base_kernel
-    if hasattr(kernel_component, "lengthscales") is False:
+    """Lengthscale rule of the post-fit pruning (waveome/utilities.py:1136-1153): a factor survives unless its
+    lengthscale is at least three times the spread (max - min) of the column it acts on; kernels without a
+    lengthscale always survive."""
+    holder = kernel_component.base_kernel if kernel_component.name == "periodic" else kernel_component
+    ell = getattr(holder, "lengthscales", None)
+    if ell is None:
         return True
-    active_index = kernel_component.active_dims[0]
-    var_range = 3 * np.ptp(X[:, active_index])
-    return kernel_component.lengthscales.numpy() < var_range
+    column = np.asarray(X)[:, holder.active_dims[0]]
+    return bool(ell.numpy() < 3.0 * (column.max() - column.min()))
 
 
 def search_through_kernel_list_(kernel_list, list_type="sum", X=None):
-    out_list = []
-    for k in kernel_list:
-        if k.name == "product":
-            out_list.append(search_through_kernel_list_(k.kernels, list_type="product", X=X))
-        elif keep_kernel_lengthscale_(k, X):
-            out_list.append(k)
-    if len(out_list) > 1:
-        return K.Sum(out_list) if list_type == "sum" else K.Product(out_list)
-    if len(out_list) == 1:
-        return out_list[0]
-    return K.Empty()
+    """Apply the lengthscale rule to the members of a Sum (or, recursively, a Product) and re-assemble what is
+    left (waveome/utilities.py:1156-1184): nothing left -> Empty(), one member -> that member, else a new
+    Sum / Product.  A product is replaced by its own pruned version (possibly Empty) and always kept."""
+    survivors = [search_through_kernel_list_(k.kernels, "product", X) if k.name == "product" else k
+                 for k in kernel_list if k.name == "product" or keep_kernel_lengthscale_(k, X)]
+    if not survivors:
+        return K.Empty()
+    if len(survivors) == 1:
+        return survivors[0]
+    return (K.Sum if list_type == "sum" else K.Product)(survivors)
 
 
 def _gaussian_logdensity(x, mu, var):
@@ -155,68 +162,65 @@ def _gaussian_logdensity(x, mu, var):
 
 def calc_deviance_explained(model, data=None, model_mu=None, model_var=None, base_mu=None, base_var=None,
                             aggregate=True, return_deviance_explained=True, return_loglik=False):
-    """Gaussian branch of waveome/utilities.py:517-611 (the likelihood on this path)."""
+    """Gaussian branch of waveome/utilities.py:517-611 (the likelihood on this path).  All three reference
+    densities share the variance var(y), so the saturated model has zero residual and the deviances are scaled
+    squared residuals: 2 (sat_ll - ll(mu)) = (y - mu)^2 / var(y) row by row."""
     y = np.asarray(data[1], dtype=np.float64)
-    y_var = np.var(y)
-    sat_ll = _gaussian_logdensity(y, y, y_var)
-    base_ll = _gaussian_logdensity(y, np.mean(y) if base_mu is None else base_mu, y_var)
-    mod_ll = _gaussian_logdensity(y, model_mu, y_var)
+    s2 = np.var(y)
+    centre = np.mean(y) if base_mu is None else base_mu
+    null_dev = np.square(y - centre) / s2
+    model_dev = np.square(y - model_mu) / s2
     if return_loglik:
-        return base_ll, mod_ll, sat_ll
+        sat_ll = np.full(np.broadcast(y, model_mu).shape, -0.5 * np.log(2 * np.pi * s2))
+        return sat_ll - 0.5 * null_dev, sat_ll - 0.5 * model_dev, sat_ll
     if aggregate:
-        null_deviance = max(0, 2 * np.sum(sat_ll - base_ll))
-        model_deviance = max(0, 2 * np.sum(sat_ll - mod_ll))
-        deviance_explained = 1 - (model_deviance / null_deviance) if null_deviance > 0 else 0
+        null_dev, model_dev = float(np.sum(null_dev)), float(np.sum(model_dev))
+        explained = 1 - model_dev / null_dev if null_dev > 0 else 0
     else:
-        null_deviance = np.clip(2 * (sat_ll - base_ll), a_min=0, a_max=np.inf)
-        model_deviance = np.clip(2 * (sat_ll - mod_ll), a_min=0, a_max=np.inf)
-        deviance_explained = 1 - np.divide(model_deviance, null_deviance,
-                                           out=np.ones_like(model_deviance, dtype="float"),
-                                           where=(null_deviance != 0))
-    if return_deviance_explained:
-        return deviance_explained
-    return null_deviance, model_deviance
+        explained = np.ones_like(model_dev, dtype=float)
+        np.divide(model_dev, null_dev, out=explained, where=null_dev != 0)
+        explained = 1 - np.where(null_dev != 0, explained, 0.0)
+    return explained if return_deviance_explained else (null_dev, model_dev)
 
 
 def calc_feature_importance_components(model, data=None, return_value="log_bf"):
-    """waveome/utilities.py:614-707: per additive component, the fit lost when the component is removed
-    from the kernel while the (whitened) variational mean is kept; last entry = 1 - deviance explained.
-    `model.component_means(data)` supplies [full, without component 0, 1, ...] training means (GPU)."""
-    de_list = []
-    k = model.kernel
-    means = model.component_means(data)
-    y = np.asarray(data[1], dtype=np.float64).reshape(-1, 1)
-    full_mu_hat = means[0].reshape(-1, 1)
-    null_lls, mod_lls, sat_lls = calc_deviance_explained(model=model, data=(data[0], y), model_mu=full_mu_hat,
-                                                         return_deviance_explained=False, aggregate=False,
-                                                         return_loglik=True)
-    if np.sum(sat_lls) >= np.sum(mod_lls) and np.sum(mod_lls) >= np.sum(null_lls):
-        full_de = 1 - (-2 * np.sum(mod_lls - sat_lls) / (-2 * np.sum(null_lls - sat_lls)))
-        full_de = max(min(1, full_de), 0)
+    """Importance of every additive component, then the residual share (waveome/utilities.py:614-707).
+
+    The reference pops one component at a time from a copy of the SVGP (keeping q_mu), predicts, and compares
+    Gaussian log-densities that all use var(y); `model.component_means(data)` returns those predictions in one
+    batched GPU call - row 0 the full model, row 1 + k the model without component k.  With a common variance the
+    log-densities differ only through residual sums of squares, so with R(.) = sum (y - mean)^2:
+        log_bf_k    = (R(without k) - R(full)) / (2 var y)             rounded to 1 decimal
+        statistic_k = max(2 log_bf_k, 0)                               rounded to 1 decimal
+        de_k        = 1 - (R(without k) - R(full)) / (R(null) - R(full)) clipped to [0, 1], 3 decimals
+    and the last entry is 1 - deviance explained = R(full) / R(null) (0 explained if the order
+    saturated >= model >= null is violated).  A single-component model is compared with the null model; a lone
+    Constant kernel scores 0."""
+    y = np.asarray(data[1], dtype=np.float64).reshape(-1)
+    means = np.asarray(model.component_means(data), dtype=np.float64).reshape(-1, len(y))
+    half_inv_var = 0.5 / np.var(y)
+    rss = np.sum(np.square(means - y[None, :]), axis=1)   # [full, without 0, without 1, ...]
+    rss_null = float(np.sum(np.square(y - y.mean())))
+    rss_full = float(rss[0])
+    explained = min(1.0, max(0.0, 1.0 - rss_full / rss_null)) if rss_full <= rss_null else 0.0
+
+    def score(rss_without):
+        gain = (rss_without - rss_full) * half_inv_var       # log Bayes factor of the full model over the reduced
+        if return_value == "log_bf":
+            return np.round(gain, 1)
+        if return_value == "statistic":
+            return max(np.round(2.0 * gain, 1), 0)
+        share = 1.0 - (rss_without - rss_full) / (rss_null - rss_full)
+        return np.round(min(1.0, max(0.0, share)), 3)
+
+    kernel = model.kernel
+    if kernel.name == "sum":
+        scores = [score(float(r)) for r in rss[1:1 + len(kernel.kernels)]]
+    elif kernel.name == "constant":
+        scores = [0.0]
+    elif return_value in ("log_bf", "statistic"):
+        gain = (rss_null - rss_full) * half_inv_var
+        scores = [np.round(gain if return_value == "log_bf" else 2.0 * gain, 1)]
     else:
-        full_de = 0
-    if k.name == "sum":
-        for k_idx in range(len(k.kernels)):
-            mod_mu_hat = means[1 + k_idx].reshape(-1, 1)
-            null_lls, sub_mod_lls, sat_lls = calc_deviance_explained(
-                model=model, data=(data[0], y), model_mu=mod_mu_hat, return_deviance_explained=False,
-                aggregate=False, return_loglik=True)
-            if return_value == "statistic":
-                scaled_de = max(np.round(-2 * (np.sum(sub_mod_lls) - np.sum(mod_lls)), 1), 0)
-            elif return_value == "log_bf":
-                scaled_de = np.round(np.sum(mod_lls) - np.sum(sub_mod_lls), 1)
-            else:
-                scaled_de = 1 - (-2 * np.sum(sub_mod_lls - mod_lls) / (-2 * np.sum(null_lls - mod_lls)))
-                scaled_de = np.round(max(min(1, scaled_de), 0), 3)
-            de_list += [scaled_de]
-    else:
-        if k.name == "constant":
-            de_list += [0.0]
-        elif return_value == "statistic":
-            de_list += [np.round(-2 * (np.sum(null_lls) - np.sum(mod_lls)), 1)]
-        elif return_value == "log_bf":
-            de_list += [np.round((np.sum(mod_lls) - np.sum(null_lls)), 1)]
-        else:
-            de_list += [np.round(full_de, 3)]
-    de_list += [np.round(1 - full_de, 3)]
-    return de_list
+        scores = [np.round(explained, 3)]
+    return scores + [np.round(1 - explained, 3)]
