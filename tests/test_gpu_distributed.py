@@ -49,11 +49,12 @@ out["sweep"] = tab[["loss", "bic", "nit"]].to_numpy()
 gps.run_search(kernels=[K.SquaredExponential(), K.Lin()], max_depth=2, keep_only_best=False)
 out["search"] = {f: {n_: m["bic"] for n_, m in gps.search_info[f]["models"].items()} for f in gps.out_names}
 out["best"] = {f: gps.search_info[f]["best_model"] for f in gps.out_names}
-with open(os.environ["WV_OUT"] + "." + os.environ.get("RANK", "s"), "wb") as fh:
-    pickle.dump(out, fh)
 if backend:
     sh = parallel.broadcast_inputs(X.to_numpy(float), Y.to_numpy(float))
     out["shared_on_device"] = bool(sh._Xt is not None and sh._Xt.is_cuda)
+with open(os.environ["WV_OUT"] + "." + os.environ.get("RANK", "s"), "wb") as fh:
+    pickle.dump(out, fh)
+if backend:
     dist.barrier()
     dist.destroy_process_group()
 '''

@@ -202,6 +202,40 @@ def test_lml_rel_error_at_n2048(ctx):
     prob.close()
 
 
+@pytest.mark.parametrize("variant", ["c2a_isotropic_se", "c2b_se_per_column"])
+def test_config_c2_verbatim_n2048(ctx, variant):
+    """BASELINE configs[1] verbatim: synthetic N = 2048, D = 3, ONE output, RBF + sigma^2 only
+    (no mean, no periodic terms): (a) isotropic SE over all three columns, (b) SE[0] + SE[1] + SE[2].
+    Value and gradient against the oracle at the GPflow defaults and at a second, perturbed point."""
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(9102 + 2)
+    N, D = 2048, 3
+    X = rng.uniform(-3, 3, size=(N, D))
+    X = (X - X.mean(0)) / X.std(0, ddof=1)
+    a, w = rng.normal(size=D), rng.uniform(0.5, 3.0, size=D)
+    y = sum(a[d] * np.sin(w[d] * X[:, d]) for d in range(D)) + 0.1 * rng.normal(size=N)
+    if variant == "c2a_isotropic_se":
+        kern = K.SquaredExponential(active_dims=[0, 1, 2])
+    else:
+        kern = K.Sum([K.SquaredExponential(active_dims=[d]) for d in range(D)])
+    ms = ModelSpec(kern, D, K.GaussianLikelihood())  # no mean function: RBF + sigma^2 alone
+    d = ms.to_dict()
+    assert d["mean"] is None
+    prob = Problem(ctx, X, y[:, None], ms, max_batch=2)
+    u0 = ms.unconstrain()
+    U = np.stack([u0, u0 + rng.normal(scale=0.3, size=len(u0))])
+    lml, st = prob.lml([0, 0], np.stack([ms.constrain(u) for u in U]))
+    loss, grad, st2 = prob.value_grad([0, 0], U)
+    for b in range(2):
+        fo, go = o.objective(d, U[b], X, y)
+        assert st[b] == 0 and st2[b] == 0
+        assert abs(lml[b] + fo) <= 1e-10 * abs(fo)            # no prior: loss = -LML
+        assert abs(loss[b] - fo) <= 1e-10 * abs(fo)
+        np.testing.assert_allclose(grad[b], go, rtol=1e-7, atol=1e-7 * np.max(np.abs(go)))
+    prob.close()
+
+
 def test_non_positive_definite_reports_inf(ctx):
     from waveome_amd.engine import Problem
 
@@ -522,8 +556,8 @@ def test_config_c3_composite_n4096(ctx):
 
 
 def test_config_c5_size_properties_n16384(ctx):
-    """configs[4] shape (N = 16384, D = 4, Matern-3/2 per column) - in float64: the float32 path of that
-    config is not built yet.  The dense oracle needs minutes at this size, so the
+    """configs[4] shape (N = 16384, D = 4, Matern-3/2 per column) in float64 (the float32 path of that config is
+    covered by tests/test_gpu_f32.py).  The dense oracle needs minutes at this size, so the
     full-size check uses size-independent properties of the LML:
       * invariance under a permutation of the rows (different 64-blocks, same value),
       * LML(s y) = -s^2/2 q - log|L| - N/2 log 2pi with q, log|L| from the s = 1 evaluation,

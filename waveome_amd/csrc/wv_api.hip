@@ -83,12 +83,13 @@ std::string build_devspec(const Spec& s, DevSpec& d) {
   for (int t = 0; t <= s.n_terms(); ++t) d.term_start[t] = s.term_start[t];
   for (int t = 0; t < s.n_terms(); ++t)
     if (s.term_start[t + 1] - s.term_start[t] > MAX_TERM_F) return "more than 4 factors in a product";
-  int nfeat = 0, nslot = 0;
-  auto feat = [&](int kind, int dim, int param) -> int {
+  int nfeat = 0, nslot = 0, nred = 0;
+  auto feat = [&](int kind, int dim, int param, int sparam) -> int {
     for (int i = 0; i < nfeat; ++i)
-      if (d.feat[i].kind == kind && d.feat[i].dim == dim && d.feat[i].param == param) return i;
+      if (d.feat[i].kind == kind && d.feat[i].dim == dim && d.feat[i].param == param && d.feat[i].sparam == sparam)
+        return i;
     if (nfeat >= MAX_FEAT) return -1;
-    d.feat[nfeat] = FeatOp{kind, dim, param, 0};
+    d.feat[nfeat] = FeatOp{kind, dim, param, sparam};
     return nfeat++;
   };
   for (size_t fi = 0; fi < s.factors.size(); ++fi) {
@@ -103,20 +104,27 @@ std::string build_devspec(const Spec& s, DevSpec& d) {
       o.p[k] = k < np ? f.param[k] : 0;
       if (k < np && s.params[f.param[k]].trainable) o.trainable |= (1 << k);
     }
+    o.nsum = f.type == WV_K_PERIODIC ? 3 : ((f.type <= WV_K_M52 || f.type == WV_K_POLY) ? 2 : (np > 0 ? 1 : 0));
+    o.sbase = -1;
+    if (o.trainable) {
+      o.sbase = nred;
+      nred += o.nsum;
+    }
     if (f.type == WV_K_EMPTY || f.type == WV_K_CONST) continue;
     for (int dim = 0; dim < s.n_dims; ++dim) {
       if (!(f.dim_mask & (1u << dim))) continue;
       int need = f.type == WV_K_PERIODIC ? 3 : 1;
       if (nslot + need > 512) return "feature slot table overflow";
       if (f.type == WV_K_PERIODIC) {
-        int a = feat(FEAT_SINPI, dim, f.param[2]), b = feat(FEAT_COSPI, dim, f.param[2]),
-            c = feat(FEAT_RAW, dim, -1);
+        // sin / cos carry the factor's lengthscale on the row side; the raw column is shared with every other factor
+        int a = feat(FEAT_SINPI, dim, f.param[2], f.param[1]), b = feat(FEAT_COSPI, dim, f.param[2], f.param[1]),
+            c = feat(FEAT_RAW, dim, -1, -1);
         if (a < 0 || b < 0 || c < 0) return "more than 64 staged features (too many periodic factors)";
         d.fslots[nslot++] = (int16_t)a;
         d.fslots[nslot++] = (int16_t)b;
         d.fslots[nslot++] = (int16_t)c;
       } else {
-        int a = feat(f.type == WV_K_CAT ? FEAT_RINT : FEAT_RAW, dim, -1);
+        int a = feat(f.type == WV_K_CAT ? FEAT_RINT : FEAT_RAW, dim, -1, -1);
         if (a < 0) return "more than 64 staged features";
         d.fslots[nslot++] = (int16_t)a;
       }
@@ -124,6 +132,7 @@ std::string build_devspec(const Spec& s, DevSpec& d) {
     }
   }
   d.n_feat = nfeat;
+  d.n_red = nred + 1;  // last slot: the noise variance
   return "";
 }
 
@@ -282,7 +291,7 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_status) hipHostFree(g.h_status);
     if (g.h_spec) hipHostFree(g.h_spec);
   }
-  void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha,
+  void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
                   p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.Kbuf32, p.Mbuf32, p.MTbuf32,
                   p.Pbuf32};
   for (void* q : ptrs)
@@ -337,6 +346,8 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
     }
     p.np_stride = std::max(p.np_stride, p.specs[si].n_params());
     p.max_feat = std::max(p.max_feat, (int)hspecs[si].n_feat);
+    p.max_fact = std::max(p.max_fact, (int)hspecs[si].n_factors);
+    p.max_red = std::max(p.max_red, (int)hspecs[si].n_red);
   }
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
   p.spec = p.specs[0];
@@ -374,6 +385,8 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
             alloc((void**)&p.dr, sizeof(double) * Np * max_batch) &&
             alloc((void**)&p.dz, sizeof(double) * Np * max_batch) &&
             alloc((void**)&p.dalpha, sizeof(double) * Np * max_batch) &&
+            alloc((void**)&p.dfeat, sizeof(double) * 2 * std::max(1, p.max_feat) * Np * max_batch) &&
+            alloc((void**)&p.dfconst, sizeof(double) * 4 * std::max(1, p.max_fact) * max_batch) &&
             alloc((void**)&p.dlogdet, sizeof(double) * p.nblk() * max_batch) &&
             alloc((void**)&p.dpart, sizeof(double) * trace_nwg(p) * np * max_batch) &&
             alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&

@@ -9,6 +9,7 @@
 //   MTbuf  [Npad][Npad]      M' (upper): K-strided image of M for the products that read M by rows
 //   Pbuf   [Npad/2+64][Npad/2+64] + [Npad][64]  L21 scratch of the recursive factorisation
 //   theta  [n_params]        constrained parameter table of the slot's fit
+//   feat   [2][max_feat][Npad]  row- and column-side kernel features (x_d, rint x_d, sinpi / cospi(x_d / period))
 //   r, z, alpha [Npad]       residual y - c, L^-1 r, K_y^-1 r
 // Npad = N rounded up to a multiple of 64; padded rows/cols of K_y are the identity so
 // log|K_y|, r' K_y^-1 r and the leading N x N block of K_y^-1 are unchanged.
@@ -37,17 +38,20 @@ struct DevFactor {
   int32_t ndims;
   int32_t slot0;      // first feature slot (see FeatOp); consecutive per active dim
   int32_t trainable;  // bit k set: parameter k of this factor is trainable
+  int32_t sbase;      // first gradient-sum slot of this factor in the trace pass (-1: nothing trainable)
+  int32_t nsum;       // gradient sums the factor's type defines (1: variance only, 2: + lengthscale / offset, 3: + period)
 };
 enum { FEAT_RAW = 0, FEAT_RINT = 1, FEAT_SINPI = 2, FEAT_COSPI = 3 };
 struct FeatOp {
   int32_t kind;
   int32_t dim;
-  int32_t param;  // period parameter for SINPI/COSPI
-  int32_t pad;
+  int32_t param;   // period parameter for SINPI/COSPI
+  int32_t sparam;  // >= 0: the ROW-side value is multiplied by sqrt(32/ln 2) / theta[sparam] (a Periodic factor's
+                   // lengthscale folded into its sin / cos features, see wv_gram.hip); -1: none
 };
 struct DevSpec {
   int32_t n_terms, n_factors, n_feat, n_params;
-  int32_t noise_param, mean_param, n_dims, pad;
+  int32_t noise_param, mean_param, n_dims, n_red;  // n_red: gradient-sum slots of the trace pass (noise included)
   int32_t term_start[65];
   DevFactor factors[128];
   FeatOp feat[MAX_FEAT];
@@ -82,6 +86,7 @@ struct GemmArgsT {
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
   int32_t latin;
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
+  int32_t prio;        // timing-experiment switches (WV_GEMM_DBG; 0 in production)
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;  // float32 storage path (wv_gemm32.hip)
@@ -152,6 +157,9 @@ struct Problem {
   int f32 = 0;
   float *Kbuf32 = nullptr, *Mbuf32 = nullptr, *MTbuf32 = nullptr, *Pbuf32 = nullptr;
   double *dtheta = nullptr, *dr = nullptr, *dz = nullptr, *dalpha = nullptr;
+  double *dfeat = nullptr;        // [max_batch][2 sides][max_feat][Npad] per-row kernel features of each slot's fit
+  double *dfconst = nullptr;      // [max_batch][max_fact][4] per-factor constants derived from theta (see wv_gram.hip)
+  int max_fact = 0, max_red = 1;  // largest n_factors / n_red over the problem's structures
   double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
   double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials

@@ -89,6 +89,7 @@ template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT, int TAG = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
+  constexpr bool DPPROT = (TAG & 2) != 0;  // experiment: rotated B fragments by DPP instead of three more LDS reads
   constexpr int NJ = BN / 32;  // B fragments per wave
   // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
   // image of half the C tile in the epilogue
@@ -197,27 +198,66 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nchunk) {
+    if (c + 1 < nchunk && !(g.prio & 4)) {
       TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, tid);
       TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, tid);
     }
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
-    if (kc0 >= wkb && kc0 < wke)
+    if (kc0 >= wkb && kc0 < wke && !(g.prio & 8))
 #pragma unroll OCC == 1 ? 4 : 1
     for (int s = 0; s < KC / 4; ++s) {
       double af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
+      if (DPPROT) {
+        // One LDS read per 16-column group; the three rotated images (column groups shifted by 4 r within the
+        // fragment's 16 lanes) come from DPP row rotations, register to register, issued between the MFMAs of
+        // the previous group (an MFMA occupies the vector issue for a fraction of its 16 cycles).
+        double b0[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NJ; ++j) b0[j] = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[0], s * 4 + fk)];
+        auto rot = [](double v, int r) -> double {
+          const int lo = __double2loint(v), hi = __double2hiint(v);
+          if (r == 1) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x12C, 0xF, 0xF, false),
+                                              __builtin_amdgcn_mov_dpp(lo, 0x12C, 0xF, 0xF, false));  // row_ror:12
+          if (r == 2) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, false),
+                                              __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, false));  // row_ror:8
+          return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, false),
+                                  __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, false));              // row_ror:4
+        };
+        double bcur[4], bnext[4];
+        bcur[0] = b0[0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double bf = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
+        for (int r = 1; r < 4; ++r) bcur[r] = rot(b0[0], r);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bcur[r], acc[i][j][r], 0, 0, 0);
+            if (j + 1 < NJ && r < 3) bnext[r + 1] = rot(b0[j + 1], r + 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // then the 2 DPP moves of the next rotation
+          }
+          if (j + 1 < NJ) {
+            bcur[0] = b0[j + 1];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) bcur[r] = bnext[r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double bf = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+          }
         }
       }
     }
@@ -235,6 +275,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   // D lane 16 i' + 4 blk + jj of accumulator (i, j, r) is row 16 i + 4 blk + i', column
   // 16 j + 4((blk + r) & 3) + jj of the wave tile. ----
   const double alpha = g.alpha, beta = g.beta;
+  if (g.prio & 2) {  // (timing experiment) keep the accumulators alive with one store
+    double sink = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sink += acc[i][j][r];
+    if (sink == 1.2345e-300) C[0] = sink;
+    return;
+  }
   constexpr int PAIRS = BN / 2;             // double2 per row
   constexpr int NROWIT = 64 * PAIRS / 256;  // row-pieces per thread per half
 #pragma unroll
@@ -269,7 +320,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
           v.x += beta * cv[it].x;
           v.y += beta * cv[it].y;
         }
-        if (TOUT != 1) *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
+        if (TOUT != 1 && (!(g.prio & 1) || v.x == 1.2345e-300)) *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
       }
     }
     if (TOUT != 0) {
@@ -327,6 +378,13 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   }
   a.tiles_live = tiles;
   {
+    // timing experiments only (results become wrong): 1 = no global C stores, 2 = no epilogue at all,
+    // 4 = no global operand loads inside the K loop, 8 = no MFMAs
+    static int dg = -1;
+    if (dg < 0) { const char* e = getenv("WV_GEMM_DBG"); dg = e ? atoi(e) : 0; }
+    a.prio = dg;
+  }
+  {
     static int rt = -1;
     if (rt < 0) { const char* e = getenv("WV_ROT_TRI"); rt = e ? atoi(e) : 0; }
     a.rot_tri = rt;
@@ -339,8 +397,14 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     const char* e = getenv("WV_GEMM_OCC");
     occ = (e && atoi(e) == 1) ? 1 : 2;
   }
+  static const bool dpp_rot = [] { const char* e = getenv("WV_GEMM_DPP"); return e && atoi(e) != 0; }();
   if (a.tag == 1 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, a);
+    if (dpp_rot) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 3>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, a);
+    return;
+  }
+  if (dpp_rot && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 2>), g, blk, 0, st, a);
     return;
   }
   if (a.tout != 0) {

@@ -9,9 +9,19 @@
 //   recomputed per tile from LDS-staged X features, so HBM traffic is one read of the lower
 //   triangle of K_y^-1 however many hyper-parameters there are.
 //
-// Both kernels stage per-row "features" of the tile's 64 rows and 64 columns in LDS:
-// raw x_d, rint(x_d) for Categorical, and sinpi(x_d/p), cospi(x_d/p) for Periodic so that
-// sin(pi (x_i - x_j)/p) = s_i c_j - c_i s_j needs no per-element trigonometry.
+// Both kernels are fp64-VALU-bound (PMC, profiles/r02_eval512_pmc_valu_*.csv: the VALU issues an fp64
+// instruction in 71-82 % of all SIMD cycles, HBM traffic is 10-12 % of the 8 TB/s roofline), so the design
+// goal is the instruction count per matrix element and term:
+//   * per-row "features" - raw x_d, rint(x_d) for Categorical, sinpi / cospi(x_d / period) for Periodic so that
+//     sin(pi (x_i - x_j)/p) = s_i c_j - c_i s_j needs no per-element trigonometry - are computed ONCE per fit and
+//     evaluation by feature_kernel into a small HBM table and copied into LDS per tile (round 1 recomputed them
+//     for each of the 528 tiles of a matrix);
+//   * exponentials go through exp2_64: the argument is produced directly in units of ln 2 / 64 (the factor's
+//     lengthscale is folded into one scalar, for Periodic into its row-side features), so that
+//     rint / subtract / 5 FMAs / one conflict-free LDS table look-up / ldexp replace the 20-instruction
+//     Cody-Waite + degree-13 polynomial of round 1;
+//   * gradient sums are accumulated as sum w e, sum w e t, sum w e q2 and scaled by the parameter-dependent
+//     constants once per tile instead of per element.
 // Thread layout: 256 threads as 16 x 16, each owning rows ty + 16a (a < 4) and 4 contiguous
 // columns 4 tx .. 4 tx + 3 (32-byte row segments -> 512 B contiguous per 16 threads).
 #include "wv_device.hpp"
@@ -21,37 +31,85 @@ namespace wv {
 constexpr double kSqrt3 = 1.7320508075688772;
 constexpr double kSqrt5 = 2.23606797749979;
 constexpr double kPi = 3.141592653589793;
+constexpr double kLn2_64 = 0.010830424696249145;    // ln 2 / 64
+constexpr double k64_Ln2 = 92.33248261689366;       // 64 / ln 2
+constexpr double kCse2 = 46.16624130844683;         // 32 / ln 2: exp(-q / (2 l^2)) = 2^(-(q * kCse2 / l^2) / 64)
+constexpr double kCse = 6.7945744023041525;         // sqrt(32 / ln 2)
+
+// 2^(j/64), j = 0..63, correctly rounded
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
+constexpr int EXPTAB_DOUBLES = 64 * 32;  // LDS image: [j][lane & 31], one private copy per lane of a half-wave
 
 struct TileCtx {
-  const double* fi;  // [n_feat][GT] row features
-  const double* fj;  // [n_feat][GT] column features
+  const double* fi;   // [n_feat][GT] row features (Periodic sin / cos already scaled by kCse / lengthscale)
+  const double* fj;   // [n_feat][GT] column features
+  const double* tab;  // exp table image in LDS, offset by this thread's lane & 31
+  const double* fc;   // [n_factors][4] constants derived from theta once per evaluation (factor_constants)
   int ty, tx;
 };
 
-// exp(x) for x <= 0 (every kernel function here exponentiates a non-positive argument): Cody-Waite reduction
-// r = x - k ln 2, |r| <= ln 2 / 2, degree-13 Taylor polynomial (truncation 4e-18 relative), scaling by ldexp.
-// The library exp spends a fifth of its instructions on overflow / special-case selects that cannot occur
-// here; arguments below -800 are clamped (the result underflows to zero either way).
-__device__ inline double exp_nonpos(double x) {
-  x = fmax(x, -800.0);
-  const double k = rint(x * 1.4426950408889634);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;  // 1/13!
-  p = fma(p, r, 2.08767569878681e-09);
-  p = fma(p, r, 2.505210838544172e-08);
-  p = fma(p, r, 2.755731922398589e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.48015873015873e-05);
-  p = fma(p, r, 1.984126984126984e-04);
-  p = fma(p, r, 1.388888888888889e-03);
-  p = fma(p, r, 8.333333333333333e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
+// Per-factor constants that depend on theta only - computed once per fit and evaluation (feature_kernel), not
+// per tile and thread: c[0] = element scale, c[1] = variance, c[2] / c[3] = what the lengthscale / period sums
+// of the gradient pass are multiplied by.
+//   SE:       t = q c0,  c0 = -(32/ln2) / l^2;        dk/dl = var e q / l^3      = c2 sum(w e t),  c2 = -var (ln2/32) / l
+//   Matern:   u = sqrt(q) c0, c0 = sqrt(nu2) (64/ln2) / l;  dk/dl = var dl / l  -> c2 = var / l
+//   Periodic: (lengthscale folded into the row features)   c2 as SE;  dk/dp = c3 sum(w e q2), c3 = var pi (ln2/32) / p^2
+__device__ inline void factor_constants(const DevFactor& f, const double* __restrict__ th, double* __restrict__ c) {
+  const int type = f.type;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+  if (type != WV_K_EMPTY) c1 = th[f.p[0]];
+  if (type == WV_K_SE) {
+    const double ell = th[f.p[1]];
+    c0 = -kCse2 / (ell * ell);
+    c2 = -c1 * (2.0 * kLn2_64) / ell;
+  } else if (type == WV_K_M12 || type == WV_K_M32 || type == WV_K_M52) {
+    const double ell = th[f.p[1]];
+    const double rt = type == WV_K_M12 ? 1.0 : (type == WV_K_M32 ? kSqrt3 : kSqrt5);
+    c0 = rt * k64_Ln2 / ell;
+    c2 = c1 / ell;
+  } else if (type == WV_K_PERIODIC) {
+    const double ell = th[f.p[1]], per = th[f.p[2]];
+    c2 = -c1 * (2.0 * kLn2_64) / ell;
+    c3 = c1 * kPi * (2.0 * kLn2_64) / (per * per);
+  } else if (type == WV_K_POLY) {
+    c0 = th[f.p[1]];  // offset
+  }
+  c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+}
+
+// 2^(t / 64) for t <= 0 (every kernel function here exponentiates a non-positive argument).
+// k = rint(t), r = t - k exactly, |r| <= 1/2: 2^(t/64) = 2^floor(k/64) * 2^((k mod 64)/64) * exp(r ln2/64); the last
+// factor by its degree-5 Taylor polynomial (|r ln2/64| <= 0.0054, truncation 3.5e-17), the middle one from the LDS
+// table - stored [j][lane & 31], so lane l of each 32-lane group reads dwords 2l, 2l+1 (mod 64) whatever its j:
+// conflict-free ds_read_b64.  ~2 ulp.  Arguments below ~ -2^31 saturate the integer conversion and underflow to 0.
+__device__ inline double exp2_64(double t, const double* __restrict__ tab) {
+  const double kd = rint(t);
+  const double r = t - kd;
+  const int k = (int)kd;
+  double p = 1.2417843701716925e-12;           // (ln2/64)^5 / 5!
+  p = fma(p, r, 5.732851688640402e-10);        // ^4 / 4!
+  p = fma(p, r, 2.1173137155464776e-07);       // ^3 / 3!
+  p = fma(p, r, 5.86490495505617e-05);         // ^2 / 2!
+  p = fma(p, r, 0.010830424696249145);         // ln2/64
   p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
+  return ldexp(tab[(k & 63) * 32] * p, k >> 6);
 }
 
 __device__ inline double ipow(double b, int e) {
@@ -60,253 +118,284 @@ __device__ inline double ipow(double b, int e) {
   return r;
 }
 
-// Stage features for `rows0..rows0+63` into dst[n_feat][GT].
-__device__ inline void stage_features(double* dst, const DevSpec* __restrict__ sp,
-                                      const double* __restrict__ X, const double* __restrict__ th,
-                                      int row0, int64_t N, int D, int tid) {
-  const int total = sp->n_feat * GT;
-  for (int q = tid; q < total; q += 256) {
-    int s = q / GT, r = q % GT;
+__device__ inline double feature_value(const FeatOp op, double x, const double* __restrict__ th, bool row_side) {
+  double v;
+  switch (op.kind) {
+    case FEAT_RINT: v = rint(x); break;
+    case FEAT_SINPI: v = sinpi(x / th[op.param]); break;
+    case FEAT_COSPI: v = cospi(x / th[op.param]); break;
+    default: v = x;
+  }
+  if (row_side && op.sparam >= 0) v *= kCse / th[op.sparam];
+  return v;
+}
+
+// Per fit and evaluation: F[b][side][slot][row], side 0 = row features, 1 = column features.
+__global__ __launch_bounds__(256) void feature_kernel(const DevSpec* __restrict__ specs,
+                                                      const int32_t* __restrict__ slot_spec,
+                                                      const double* __restrict__ X,
+                                                      const double* __restrict__ theta_all,
+                                                      double* __restrict__ F, double* __restrict__ FC,
+                                                      int64_t N, int64_t Npad, int D, int max_feat, int max_fact,
+                                                      int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+  const double* th = theta_all + (int64_t)b * sp->n_params;
+  if (blockIdx.x == 0 && (int)threadIdx.x < sp->n_factors)
+    factor_constants(sp->factors[threadIdx.x], th, FC + ((int64_t)b * max_fact + threadIdx.x) * 4);
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= Npad) return;
+  double* Fr = F + (int64_t)b * 2 * max_feat * Npad;
+  double* Fc = Fr + (int64_t)max_feat * Npad;
+  for (int s = 0; s < sp->n_feat; ++s) {
     const FeatOp op = sp->feat[s];
-    int64_t row = row0 + r;
-    double x = (row < N) ? X[row * D + op.dim] : 0.0;
-    double v;
-    switch (op.kind) {
-      case FEAT_RINT: v = rint(x); break;
-      case FEAT_SINPI: v = sinpi(x / th[op.param]); break;
-      case FEAT_COSPI: v = cospi(x / th[op.param]); break;
-      default: v = x;
-    }
-    dst[q] = v;
+    const double x = (row < N) ? X[row * D + op.dim] : 0.0;
+    const double base = feature_value(op, x, th, false);
+    Fc[(int64_t)s * Npad + row] = base;
+    Fr[(int64_t)s * Npad + row] = (op.sparam >= 0) ? base * (kCse / th[op.sparam]) : base;
   }
 }
 
-// Evaluate one factor on the thread's 4x4 elements.
-// GRAD == false: k[a][c] = factor value.
-// GRAD == true : additionally contracts wo[a][c] * dk/dparam_q into s[q] (q < 3).
-template <bool GRAD>
-__device__ inline void eval_factor(const DevFactor& f, const int16_t* __restrict__ slots,
-                                   const double* __restrict__ th, const TileCtx& t,
-                                   double (&k)[4][4], const double (&wo)[4][4], double (&s)[3]) {
-  const int type = f.type;
-  double q[4][4], q2[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { q[a][c] = 0.0; q2[a][c] = 0.0; }
-
-  if (type == WV_K_PERIODIC) {
-    for (int d = 0; d < f.ndims; ++d) {
-      const int ss = slots[f.slot0 + 3 * d], sc = slots[f.slot0 + 3 * d + 1], sr = slots[f.slot0 + 3 * d + 2];
-      double si[4], ci[4], xi[4], sj[4], cj[4], xj[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        si[a] = t.fi[ss * GT + t.ty + 16 * a];
-        ci[a] = t.fi[sc * GT + t.ty + 16 * a];
-        xi[a] = t.fi[sr * GT + t.ty + 16 * a];
-        sj[a] = t.fj[ss * GT + 4 * t.tx + a];
-        cj[a] = t.fj[sc * GT + 4 * t.tx + a];
-        xj[a] = t.fj[sr * GT + 4 * t.tx + a];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sn = si[a] * cj[c] - ci[a] * sj[c];  // sin(pi (xi-xj)/p)
-          q[a][c] += sn * sn;
-          if (GRAD) {
-            double cs = ci[a] * cj[c] + si[a] * sj[c];  // cos(pi (xi-xj)/p)
-            q2[a][c] += (xi[a] - xj[c]) * sn * cs;
-          }
-        }
-    }
-  } else if (type == WV_K_CAT) {
-    const int sl = slots[f.slot0];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double ri = t.fi[sl * GT + t.ty + 16 * a];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) q[a][c] = (ri == t.fj[sl * GT + 4 * t.tx + c]) ? 1.0 : 0.0;
-    }
-  } else if (type == WV_K_LIN || type == WV_K_POLY) {
-    for (int d = 0; d < f.ndims; ++d) {
-      const int sl = slots[f.slot0 + d];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        double xi = t.fi[sl * GT + t.ty + 16 * a];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[a][c] += xi * t.fj[sl * GT + 4 * t.tx + c];
-      }
-    }
-  } else if (type <= WV_K_M52) {  // SE / Matern: squared distance
-    for (int d = 0; d < f.ndims; ++d) {
-      const int sl = slots[f.slot0 + d];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        double xi = t.fi[sl * GT + t.ty + 16 * a];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double df = xi - t.fj[sl * GT + 4 * t.tx + c];
-          q[a][c] += df * df;
-        }
-      }
-    }
+// tile staging: copy 64 rows of every feature slot from the table into LDS
+__device__ inline void stage_from_table(double* dst, const double* __restrict__ Fside, int n_feat, int64_t Npad,
+                                        int row0, int tid) {
+  for (int q = tid; q < n_feat * GT; q += 256) dst[q] = Fside[(int64_t)(q / GT) * Npad + row0 + (q % GT)];
+}
+// ... or compute them in place (rectangular cross-Gram of the prediction path: new rows have no table)
+__device__ inline void stage_features(double* dst, const DevSpec* __restrict__ sp, const double* __restrict__ X,
+                                      const double* __restrict__ th, int row0, int64_t N, int D, int tid,
+                                      bool row_side) {
+  const int total = sp->n_feat * GT;
+  for (int q = tid; q < total; q += 256) {
+    const int s = q / GT, r = q % GT;
+    const FeatOp op = sp->feat[s];
+    const int64_t row = row0 + r;
+    dst[q] = feature_value(op, (row < N) ? X[row * D + op.dim] : 0.0, th, row_side);
   }
+}
+__device__ inline void stage_exp_table(double* tab, int tid) {
+  for (int q = tid; q < EXPTAB_DOUBLES; q += 256) tab[q] = kExp2Tab[q >> 5];
+}
 
+// One factor on the thread's 4 x 4 elements.
+//   MODE 0: k[a][c]  = factor value                        (a factor of a product)
+//   MODE 1: k[a][c] += factor value                        (a single-factor term, accumulated into the sum)
+//   MODE 2: s[m] = sum_ac wo[a][c] dk[a][c]/dparam_m, m < 3  (gradient contraction; k is not written)
+//   MODE 3: k[a][c] *= factor value                        (further factors of a product, in place)
+// Single-column factors (what full_kernel_build produces) take fused paths that never materialise a 4 x 4
+// distance array; WV_ROW_FENCE keeps the scheduler from interleaving all 16 exponential chains at once
+// (4 in flight per wave are enough beside 2-3 resident waves, 16 cost ~60 more VGPRs and spill).
+#define WV_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int MODE>
+__device__ inline void factor_tile(const DevFactor& f, const double* __restrict__ fc,
+                                   const int16_t* __restrict__ slots, const TileCtx& t, double (&k)[4][4],
+                                   const double (&wo)[4][4], double (&s)[3]) {
+  const int type = f.type;
+  const double c0 = fc[0], var = fc[1];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  switch (type) {
-    case WV_K_SE: {
-      const double var = th[f.p[0]], ell = th[f.p[1]];
-      const double hi = -0.5 / (ell * ell), i3 = 1.0 / (ell * ell * ell);
+  auto emit = [&](int a, int c, double val) {
+    if (MODE == 1) k[a][c] += val;
+    else if (MODE == 0) k[a][c] = val;
+    else if (MODE == 3) k[a][c] *= val;
+  };
+  if (type == WV_K_SE || type == WV_K_M12 || type == WV_K_M32 || type == WV_K_M52) {
+    // per-element work given the squared distance q on the factor's columns
+    auto elem = [&](int a, int c, double q) {
+      if (type == WV_K_SE) {
+        const double tt = q * c0, e = exp2_64(tt, t.tab);
+        if (MODE == 2) { const double we = wo[a][c] * e; s0 += we; s1 = fma(we, tt, s1); }
+        else emit(a, c, var * e);
+      } else {
+        const double u = sqrt(q) * c0, e = exp2_64(-u, t.tab), z = u * kLn2_64;
+        double gg, dl;  // k = var gg, dk/dl = var dl / l
+        if (type == WV_K_M12) { gg = e; dl = z * e; }
+        else if (type == WV_K_M32) { gg = (1.0 + z) * e; dl = z * z * e; }
+        else { const double z23 = z * z * (1.0 / 3.0); gg = (1.0 + z + z23) * e; dl = z23 * (1.0 + z) * e; }
+        if (MODE == 2) { s0 = fma(wo[a][c], gg, s0); s1 = fma(wo[a][c], dl, s1); }
+        else emit(a, c, var * gg);
+      }
+    };
+    if (f.ndims == 1) {
+      const int sl = slots[f.slot0];
+      double xj[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int c = 0; c < 4; ++c) xj[c] = t.fj[sl * GT + 4 * t.tx + c];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double xi = t.fi[sl * GT + t.ty + 16 * a];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          double e = exp_nonpos(q[a][c] * hi);
-          k[a][c] = var * e;
-          if (GRAD) { s0 += wo[a][c] * e; s1 += wo[a][c] * (var * e * q[a][c] * i3); }
+          const double df = xi - xj[c];  // differences first: no cancellation for short lengthscales
+          elem(a, c, df * df);
         }
-    } break;
-    case WV_K_M12: {
-      const double var = th[f.p[0]], ell = th[f.p[1]], iell = 1.0 / ell;
+        WV_ROW_FENCE();
+      }
+    } else {
+      double q[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sr = sqrt(q[a][c]) * iell, e = exp_nonpos(-sr);
-          k[a][c] = var * e;
-          if (GRAD) { s0 += wo[a][c] * e; s1 += wo[a][c] * (var * e * sr * iell); }
-        }
-    } break;
-    case WV_K_M32: {
-      const double var = th[f.p[0]], ell = th[f.p[1]], iell = 1.0 / ell;
+        for (int c = 0; c < 4; ++c) q[a][c] = 0.0;
+      for (int d = 0; d < f.ndims; ++d) {
+        const int sl = slots[f.slot0 + d];
+        double xj[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 4; ++c) xj[c] = t.fj[sl * GT + 4 * t.tx + c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sr = sqrt(q[a][c]) * iell, e = exp_nonpos(-kSqrt3 * sr), gg = (1.0 + kSqrt3 * sr) * e;
-          k[a][c] = var * gg;
-          if (GRAD) { s0 += wo[a][c] * gg; s1 += wo[a][c] * (var * 3.0 * sr * sr * e * iell); }
-        }
-    } break;
-    case WV_K_M52: {
-      const double var = th[f.p[0]], ell = th[f.p[1]], iell = 1.0 / ell;
+        for (int a = 0; a < 4; ++a) {
+          const double xi = t.fi[sl * GT + t.ty + 16 * a];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sr = sqrt(q[a][c]) * iell, e = exp_nonpos(-kSqrt5 * sr);
-          double gg = (1.0 + kSqrt5 * sr + (5.0 / 3.0) * sr * sr) * e;
-          k[a][c] = var * gg;
-          if (GRAD) {
-            s0 += wo[a][c] * gg;
-            s1 += wo[a][c] * (var * (5.0 / 3.0) * sr * sr * (1.0 + kSqrt5 * sr) * e * iell);
+          for (int c = 0; c < 4; ++c) {
+            const double df = xi - xj[c];
+            q[a][c] = fma(df, df, q[a][c]);
           }
         }
-    } break;
-    case WV_K_PERIODIC: {
-      const double var = th[f.p[0]], ell = th[f.p[1]], per = th[f.p[2]];
-      const double hi = -0.5 / (ell * ell), i3 = 1.0 / (ell * ell * ell);
-      const double cp = kPi / (per * per * ell * ell);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) elem(a, c, q[a][c]);
+        WV_ROW_FENCE();
+      }
+    }
+    s1 *= fc[2];
+  } else if (type == WV_K_PERIODIC) {
+    // t = -sum_d (b sin(pi (x_i - x_j)/p))^2 with b = kCse / l folded into the ROW-side sin / cos features
+    auto elem = [&](int a, int c, double tt, double q2) {
+      const double e = exp2_64(tt, t.tab);
+      if (MODE == 2) {
+        const double we = wo[a][c] * e;
+        s0 += we;
+        s1 = fma(we, tt, s1);
+        s2 = fma(we, q2, s2);
+      } else emit(a, c, var * e);
+    };
+    if (f.ndims == 1) {
+      const int ss = slots[f.slot0], sc = slots[f.slot0 + 1], sr = slots[f.slot0 + 2];
+      double sj[4], cj[4], xj[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sj[c] = t.fj[ss * GT + 4 * t.tx + c];
+        cj[c] = t.fj[sc * GT + 4 * t.tx + c];
+        xj[c] = MODE == 2 ? t.fj[sr * GT + 4 * t.tx + c] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double si = t.fi[ss * GT + t.ty + 16 * a], ci = t.fi[sc * GT + t.ty + 16 * a];
+        const double xi = MODE == 2 ? t.fi[sr * GT + t.ty + 16 * a] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double sn = fma(si, cj[c], -(ci * sj[c]));
+          double q2 = 0.0;
+          if (MODE == 2) q2 = (xi - xj[c]) * sn * fma(ci, cj[c], si * sj[c]);
+          elem(a, c, -(sn * sn), q2);
+        }
+        WV_ROW_FENCE();
+      }
+    } else {
+      double tt[4][4], q2[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
+        for (int c = 0; c < 4; ++c) { tt[a][c] = 0.0; q2[a][c] = 0.0; }
+      for (int d = 0; d < f.ndims; ++d) {
+        const int ss = slots[f.slot0 + 3 * d], sc = slots[f.slot0 + 3 * d + 1], sr = slots[f.slot0 + 3 * d + 2];
+        double sj[4], cj[4], xj[4];
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
-          double e = exp_nonpos(q[a][c] * hi), kk = var * e;
-          k[a][c] = kk;
-          if (GRAD) {
-            s0 += wo[a][c] * e;
-            s1 += wo[a][c] * (kk * q[a][c] * i3);
-            s2 += wo[a][c] * (kk * cp * q2[a][c]);
+          sj[c] = t.fj[ss * GT + 4 * t.tx + c];
+          cj[c] = t.fj[sc * GT + 4 * t.tx + c];
+          xj[c] = MODE == 2 ? t.fj[sr * GT + 4 * t.tx + c] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const double si = t.fi[ss * GT + t.ty + 16 * a], ci = t.fi[sc * GT + t.ty + 16 * a];
+          const double xi = MODE == 2 ? t.fi[sr * GT + t.ty + 16 * a] : 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double sn = fma(si, cj[c], -(ci * sj[c]));
+            tt[a][c] = fma(-sn, sn, tt[a][c]);
+            if (MODE == 2) q2[a][c] = fma((xi - xj[c]) * sn, fma(ci, cj[c], si * sj[c]), q2[a][c]);
           }
         }
-    } break;
-    case WV_K_LIN: {
-      const double var = th[f.p[0]];
+      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          k[a][c] = var * q[a][c];
-          if (GRAD) s0 += wo[a][c] * q[a][c];
+        for (int c = 0; c < 4; ++c) elem(a, c, tt[a][c], q2[a][c]);
+        WV_ROW_FENCE();
+      }
+    }
+    s1 *= fc[2];
+    s2 *= fc[3];
+  } else if (type == WV_K_LIN || type == WV_K_POLY || type == WV_K_CAT) {
+    double q[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) q[a][c] = 0.0;
+    if (type == WV_K_CAT) {
+      const int sl = slots[f.slot0];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double ri = t.fi[sl * GT + t.ty + 16 * a];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[a][c] = (ri == t.fj[sl * GT + 4 * t.tx + c]) ? 1.0 : 0.0;
+      }
+    } else {
+      for (int d = 0; d < f.ndims; ++d) {
+        const int sl = slots[f.slot0 + d];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const double xi = t.fi[sl * GT + t.ty + 16 * a];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) q[a][c] = fma(xi, t.fj[sl * GT + 4 * t.tx + c], q[a][c]);
         }
-    } break;
-    case WV_K_POLY: {
-      const double var = th[f.p[0]], off = th[f.p[1]];
+      }
+    }
+    if (type == WV_K_POLY) {
+      const double off = c0;
       const int deg = f.degree;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          double base = var * q[a][c] + off;
-          double pm1 = ipow(base, deg - 1);
-          k[a][c] = pm1 * base;
-          if (GRAD) { double dk = deg * pm1; s0 += wo[a][c] * dk * q[a][c]; s1 += wo[a][c] * dk; }
+          const double base = var * q[a][c] + off, pm1 = ipow(base, deg - 1);
+          if (MODE == 2) { const double dk = deg * pm1 * wo[a][c]; s0 = fma(dk, q[a][c], s0); s1 += dk; }
+          else emit(a, c, pm1 * base);
         }
-    } break;
-    case WV_K_CONST: {
-      const double var = th[f.p[0]];
+    } else {  // Lin, Categorical: k = var q, dk/dvar = q
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          k[a][c] = var;
-          if (GRAD) s0 += wo[a][c];
+          if (MODE == 2) s0 = fma(wo[a][c], q[a][c], s0);
+          else emit(a, c, var * q[a][c]);
         }
-    } break;
-    case WV_K_CAT: {
-      const double var = th[f.p[0]];
+    }
+  } else if (type == WV_K_CONST) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          k[a][c] = var * q[a][c];
-          if (GRAD) s0 += wo[a][c] * q[a][c];
-        }
-    } break;
-    default:  // WV_K_EMPTY
+      for (int c = 0; c < 4; ++c) {
+        if (MODE == 2) s0 += wo[a][c];
+        else emit(a, c, var);
+      }
+  } else {  // WV_K_EMPTY
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) k[a][c] = 0.0;
+      for (int c = 0; c < 4; ++c) emit(a, c, 0.0);
   }
-  if (GRAD) { s[0] = s0; s[1] = s1; s[2] = s2; }
+  if (MODE == 2) { s[0] = s0; s[1] = s1; s[2] = s2; }
 }
 
-// lower-triangular tile index -> (ti, tj), ti >= tj
-__device__ inline void tri_decode(int t, int& ti, int& tj) {
-  int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((i + 1) * (i + 2) / 2 <= t) ++i;
-  while (i * (i + 1) / 2 > t) --i;
-  ti = i;
-  tj = t - i * (i + 1) / 2;
-}
-
-template <typename R>
-__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
-                                                   const int32_t* __restrict__ slot_spec,
-                                                   const double* __restrict__ X,
-                                                   const double* __restrict__ theta_all,
-                                                   R* __restrict__ Kall, int64_t N,
-                                                   int64_t Npad, int D, int slot0, int write_upper,
-                                                   uint64_t term_mask, double diag_override) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = slot0 + blockIdx.y;
-  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+// sum over (unmasked) terms of the product of their factors, on the thread's 4 x 4 elements
+__device__ inline void kernel_sum_tile(const DevSpec* __restrict__ sp, const TileCtx& t, uint64_t term_mask,
+                                       double (&sum)[4][4]) {
   const int16_t* slots = sp->fslots;
-  const double* th = theta_all + (int64_t)b * sp->n_params;
-  R* K = Kall + (int64_t)b * Npad * Npad;
-  int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
-  const int tid = threadIdx.x;
-  double* fi = smem;
-  double* fj = smem + sp->n_feat * GT;
-  stage_features(fi, sp, X, th, ti * GT, N, D, tid);
-  stage_features(fj, sp, X, th, tj * GT, N, D, tid);
-  __syncthreads();
-
-  TileCtx t{fi, fj, tid >> 4, tid & 15};
-  double sum[4][4], k[4][4], prod[4][4], dummy_w[4][4], dummy_s[3];
+  double prod[4][4], dummy_s[3];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -314,41 +403,87 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
   for (int term = 0; term < sp->n_terms; ++term) {
     if (!((term_mask >> term) & 1ull)) continue;  // leave-component-out Gram matrices
     const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
-    for (int f = f0; f < f1; ++f) {
-      eval_factor<false>(sp->factors[f], slots, th, t, k, dummy_w, dummy_s);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) prod[a][c] = (f == f0) ? k[a][c] : prod[a][c] * k[a][c];
+    if (f1 - f0 == 1) {
+      factor_tile<1>(sp->factors[f0], t.fc + 4 * f0, slots, t, sum, sum, dummy_s);
+      continue;
     }
+    factor_tile<0>(sp->factors[f0], t.fc + 4 * f0, slots, t, prod, prod, dummy_s);
+    for (int f = f0 + 1; f < f1; ++f) factor_tile<3>(sp->factors[f], t.fc + 4 * f, slots, t, prod, prod, dummy_s);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) sum[a][c] += prod[a][c];
   }
+}
+
+// lower-triangular tile index -> (ti, tj), ti >= tj
+__device__ inline void tri_decode(int t, int& ti, int& tj) {
+  int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  while (i * (i + 1) / 2 > t) --i;
+  ti = i;
+  tj = t - i * (i + 1) / 2;
+}
+
+constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup)
+
+template <typename R>
+__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
+                                                   const int32_t* __restrict__ slot_spec,
+                                                   const double* __restrict__ F, const double* __restrict__ FC,
+                                                   const double* __restrict__ theta_all,
+                                                   R* __restrict__ Kall, int64_t N,
+                                                   int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
+                                                   int write_upper, uint64_t term_mask, double diag_override) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = slot0 + blockIdx.y;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+  const double* th = theta_all + (int64_t)b * sp->n_params;
+  R* K = Kall + (int64_t)b * Npad * Npad;
+  const int tid = threadIdx.x;
+  double* tab = smem;
+  double* fi = smem + EXPTAB_DOUBLES;
+  double* fj = fi + sp->n_feat * GT;
+  const double* Fr = F + (int64_t)b * 2 * max_feat * Npad;
+  const double* Fc = Fr + (int64_t)max_feat * Npad;
+  stage_exp_table(tab, tid);
+  TileCtx t{fi, fj, tab + (tid & 31), FC + (int64_t)b * max_fact * 4, tid >> 4, tid & 15};
   const double noise = diag_override >= 0.0 ? diag_override : th[sp->noise_param];
+  for (int tt = 0; tt < GRAM_TPW; ++tt) {
+    const int tile = blockIdx.x * GRAM_TPW + tt;
+    if (tile >= ntiles) break;
+    int ti, tj;
+    tri_decode(tile, ti, tj);
+    __syncthreads();
+    stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
+    stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
+    __syncthreads();
+    double sum[4][4];
+    kernel_sum_tile(sp, t, term_mask, sum);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
-    double v[4];
+    for (int a = 0; a < 4; ++a) {
+      const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
+      double v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
-      double x = sum[a][c];
-      if (i == j) x += noise;
-      if (i >= N || j >= N) x = (i == j) ? 1.0 : 0.0;  // identity padding
-      v[c] = x;
-    }
-    store4(K + i * Npad + (int64_t)tj * GT + 4 * t.tx, v);
-    if (write_upper && ti != tj) {
+      for (int c = 0; c < 4; ++c) {
+        const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
+        double x = sum[a][c];
+        if (i == j) x += noise;
+        if (i >= N || j >= N) x = (i == j) ? 1.0 : 0.0;  // identity padding
+        v[c] = x;
+      }
+      store4(K + i * Npad + (int64_t)tj * GT + 4 * t.tx, v);
+      if (write_upper && ti != tj) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) K[((int64_t)tj * GT + 4 * t.tx + c) * Npad + i] = (R)v[c];
+        for (int c = 0; c < 4; ++c) K[((int64_t)tj * GT + 4 * t.tx + c) * Npad + i] = (R)v[c];
+      }
     }
   }
 }
 
 // Rectangular cross-Gram K(Xrow, Xcol) for prediction at new inputs: rows = Mrow new points,
-// columns = the N training points, no noise, padded entries zero.  One 64 x 64 tile per workgroup.
+// columns = the N training points, no noise, padded entries zero.  One 64 x 64 tile per workgroup; features
+// and factor constants are computed in place (the new rows have no feature table).
 __global__ __launch_bounds__(256) void gram_rect_kernel(const DevSpec* __restrict__ sp,
                                                         const double* __restrict__ Xrow,
                                                         const double* __restrict__ Xcol,
@@ -356,34 +491,20 @@ __global__ __launch_bounds__(256) void gram_rect_kernel(const DevSpec* __restric
                                                         double* __restrict__ out, int64_t Mrow,
                                                         int64_t N, int64_t ldo, int D, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int16_t* slots = sp->fslots;
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n;
   const int tid = threadIdx.x;
-  double* fi = smem;
-  double* fj = smem + sp->n_feat * GT;
-  stage_features(fi, sp, Xrow, th, ti * GT, Mrow, D, tid);
-  stage_features(fj, sp, Xcol, th, tj * GT, N, D, tid);
+  double* tab = smem;
+  double* fi = smem + EXPTAB_DOUBLES;
+  double* fj = fi + sp->n_feat * GT;
+  double* fcl = fj + sp->n_feat * GT;  // [n_factors][4]
+  stage_exp_table(tab, tid);
+  stage_features(fi, sp, Xrow, th, ti * GT, Mrow, D, tid, true);
+  stage_features(fj, sp, Xcol, th, tj * GT, N, D, tid, false);
+  if (tid < sp->n_factors) factor_constants(sp->factors[tid], th, fcl + 4 * tid);
   __syncthreads();
-  TileCtx t{fi, fj, tid >> 4, tid & 15};
-  double sum[4][4], k[4][4], prod[4][4], dummy_w[4][4], dummy_s[3];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sum[a][c] = 0.0;
-  for (int term = 0; term < sp->n_terms; ++term) {
-    const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
-    for (int f = f0; f < f1; ++f) {
-      eval_factor<false>(sp->factors[f], slots, th, t, k, dummy_w, dummy_s);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) prod[a][c] = (f == f0) ? k[a][c] : prod[a][c] * k[a][c];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) sum[a][c] += prod[a][c];
-  }
+  TileCtx t{fi, fj, tab + (tid & 31), fcl, tid >> 4, tid & 15};
+  double sum[4][4];
+  kernel_sum_tile(sp, t, ~0ull, sum);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
@@ -403,7 +524,7 @@ void launch_gram_rect(Problem& p, hipStream_t st, const double* dXnew, int64_t M
                       const double* dtheta_row, double* out) {
   const int tiles_n = (int)(p.Npad / GT);
   dim3 grid((unsigned)((Mpad / GT) * tiles_n)), blk(256);
-  size_t sh = (size_t)2 * p.hspec.n_feat * GT * sizeof(double);  // (prediction: structure 0)
+  size_t sh = ((size_t)2 * p.hspec.n_feat * GT + EXPTAB_DOUBLES + 4 * p.hspec.n_factors) * sizeof(double);  // (structure 0)
   hipLaunchKernelGGL(gram_rect_kernel, grid, blk, sh, st, p.dspec, dXnew, p.dX, dtheta_row, out, Mrow, p.N,
                      p.Npad, p.D, tiles_n);
 }
@@ -414,34 +535,61 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+// sum over the 4 lanes of a quad, result in every lane of it: two DPP quad permutes (register to register,
+// no LDS round trip - the full 64-lane reductions of round 1 were a chain of six ds_bpermute latencies per sum)
+__device__ inline double quad_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false),
+                        __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+  lo = __double2loint(v);
+  hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false),
+                        __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+  return v;
+}
+
 constexpr int TRACE_TPW = 4;  // tiles per workgroup
 
 // part[b][wg][p] = sum over this workgroup's tiles of  w_ij W_ij dK_ij/dtheta_p
 // (w = 1 below the diagonal, 1/2 on it, 0 above; noise_param gets 1/2 W_ii).
+// Every (trainable factor, parameter) pair owns a "sum slot" (DevFactor::sbase); a thread's contribution is
+// reduced over its quad in registers and added to the slot's 64 per-quad accumulators in LDS (ds_add_f64, fire
+// and forget); one full reduction per slot happens at the very end of the workgroup instead of one per slot, factor
+// and tile.
 template <typename R>
-__global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ specs,
+__global__ __launch_bounds__(256, 2) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
-                                                    const double* __restrict__ X,
+                                                    const double* __restrict__ F, const double* __restrict__ FC,
                                                     const double* __restrict__ theta_all,
                                                     const R* __restrict__ Kinv_all,
                                                     const double* __restrict__ alpha_all,
                                                     double* __restrict__ part, int64_t N,
-                                                    int64_t Npad, int D, int slot0, int ntiles,
+                                                    int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
                                                     int nwg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const int16_t* slots = sp->fslots;
-  const int np = sp->n_params;
-  const double* th = theta_all + (int64_t)b * np;
+  const int np = sp->n_params, nred = sp->n_red;
   const R* Kinv = Kinv_all + (int64_t)b * Npad * Npad;
   const double* alpha = alpha_all + (int64_t)b * Npad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* fi = smem;
+  const double* Fr = F + (int64_t)b * 2 * max_feat * Npad;
+  const double* Fc = Fr + (int64_t)max_feat * Npad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = tid >> 2;
+  const bool quad_leader = (tid & 3) == 0;
+  double* tab = smem;
+  double* fi = smem + EXPTAB_DOUBLES;
   double* fj = fi + sp->n_feat * GT;
-  double* acc = fj + sp->n_feat * GT;  // [4 waves][np]
-  for (int q = tid; q < 4 * np; q += 256) acc[q] = 0.0;
-  TileCtx t{fi, fj, tid >> 4, tid & 15};
+  double* red = fj + sp->n_feat * GT;  // [nred][64 quads]
+  double* pacc = red + nred * 64;      // [np]
+  stage_exp_table(tab, tid);
+  for (int q = tid; q < nred * 64; q += 256) red[q] = 0.0;
+  for (int q = tid; q < np; q += 256) pacc[q] = 0.0;
+  TileCtx t{fi, fj, tab + (tid & 31), FC + (int64_t)b * max_fact * 4, tid >> 4, tid & 15};
+  auto contribute = [&](int slot, double v) {
+    v = quad_sum(v);
+    if (quad_leader) __hip_atomic_fetch_add(&red[slot * 64 + quad], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
 
   for (int tt = 0; tt < TRACE_TPW; ++tt) {
     const int tile = blockIdx.x * TRACE_TPW + tt;
@@ -449,8 +597,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
     int ti, tj;
     tri_decode(tile, ti, tj);
     __syncthreads();
-    stage_features(fi, sp, X, th, ti * GT, N, D, tid);
-    stage_features(fj, sp, X, th, tj * GT, N, D, tid);
+    stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
+    stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
     __syncthreads();
 
     // weights: W_ij = alpha_i alpha_j - Kinv_ij with the symmetry / padding mask folded in
@@ -474,65 +622,81 @@ __global__ __launch_bounds__(256) void trace_kernel(const DevSpec* __restrict__ 
         if (i == j) snoise += w[a][c];
       }
     }
-    if (ti == tj) {  // wave-uniform
-      double r = wave_sum(snoise);
-      if (lane == 0) acc[wave * np + sp->noise_param] += r;
-    }
+    if (ti == tj) contribute(nred - 1, snoise);  // (workgroup-uniform branch)
 
     for (int term = 0; term < sp->n_terms; ++term) {
       const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
       for (int g = f0; g < f1; ++g) {
         const DevFactor fg = sp->factors[g];
         if (fg.trainable == 0) continue;
-        double wo[4][4], k[4][4], s[3];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) wo[a][c] = w[a][c];
-        for (int f = f0; f < f1; ++f) {
-          if (f == g) continue;
-          eval_factor<false>(sp->factors[f], slots, th, t, k, wo, s);
+        double s[3], unused[4][4];
+        if (f1 - f0 == 1) {
+          factor_tile<2>(fg, t.fc + 4 * g, slots, t, unused, w, s);
+        } else {
+          double wo[4][4];
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wo[a][c] *= k[a][c];
+            for (int c = 0; c < 4; ++c) wo[a][c] = w[a][c];
+          for (int f = f0; f < f1; ++f)
+            if (f != g) factor_tile<3>(sp->factors[f], t.fc + 4 * f, slots, t, wo, wo, s);
+          factor_tile<2>(fg, t.fc + 4 * g, slots, t, unused, wo, s);
         }
-        eval_factor<true>(fg, slots, th, t, k, wo, s);
-        double r0 = wave_sum(s[0]), r1 = wave_sum(s[1]), r2 = wave_sum(s[2]);
-        if (lane == 0) {
-          if (fg.trainable & 1) acc[wave * np + fg.p[0]] += r0;
-          if (fg.trainable & 2) acc[wave * np + fg.p[1]] += r1;
-          if (fg.trainable & 4) acc[wave * np + fg.p[2]] += r2;
-        }
+        contribute(fg.sbase, s[0]);
+        if (fg.nsum > 1) contribute(fg.sbase + 1, s[1]);
+        if (fg.nsum > 2) contribute(fg.sbase + 2, s[2]);
       }
     }
   }
   __syncthreads();
+  // one 64-lane reduction per slot (wave w takes slots w, w + 4, ...); the total goes back into red[slot * 64]
+  for (int sidx = wave; sidx < nred; sidx += 4) {
+    const double v = wave_sum(red[sidx * 64 + lane]);
+    if (lane == 0) red[sidx * 64] = v;
+  }
+  __syncthreads();
+  // slots -> parameters (a parameter shared by several factors collects all of them)
+  for (int f = tid; f < sp->n_factors; f += 256) {
+    const DevFactor ff = sp->factors[f];
+    if (ff.sbase < 0) continue;
+    for (int m = 0; m < ff.nsum; ++m)
+      if (ff.trainable & (1 << m))
+        __hip_atomic_fetch_add(&pacc[ff.p[m]], red[(ff.sbase + m) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[(nred - 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
   double* out = part + ((int64_t)b * nwg + blockIdx.x) * np;
-  for (int p = tid; p < np; p += 256) out[p] = acc[p] + acc[np + p] + acc[2 * np + p] + acc[3 * np + p];
+  for (int p = tid; p < np; p += 256) out[p] = pacc[p];
+}
+
+static void launch_features(Problem& p, hipStream_t st, int slot0, int nb) {
+  dim3 grid((unsigned)((p.Npad + 255) / 256), nb), blk(256);
+  hipLaunchKernelGGL(feature_kernel, grid, blk, 0, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.dfeat, p.dfconst, p.N,
+                     p.Npad, p.D, p.max_feat, p.max_fact, slot0);
+}
+
+static size_t gram_lds_bytes(const Problem& p) { return ((size_t)2 * p.max_feat * GT + EXPTAB_DOUBLES) * sizeof(double); }
+static int gram_nwg(const Problem& p) { return (p.ntiles() + GRAM_TPW - 1) / GRAM_TPW; }
+
+template <typename R>
+static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb, int write_upper, uint64_t term_mask,
+                          double diag) {
+  dim3 grid(gram_nwg(p), nb), blk(256);
+  hipLaunchKernelGGL(gram_kernel<R>, grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,
+                     p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), write_upper, term_mask, diag);
 }
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
-  dim3 grid(p.ntiles(), nb), blk(256);
-  size_t sh = (size_t)2 * p.max_feat * GT * sizeof(double);
-  if (p.f32)
-    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad, p.D,
-                       slot0, 0, term_mask, diag);
-  else
-    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad, p.D,
-                       slot0, 0, term_mask, diag);
+  launch_features(p, st, slot0, nb);  // (the parameter rows of these slots may have changed since the last call)
+  if (p.f32) launch_gram_t<float>(p, st, p.Kbuf32, slot0, nb, 0, term_mask, diag);
+  else launch_gram_t<double>(p, st, p.Kbuf, slot0, nb, 0, term_mask, diag);
 }
 
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper) {
-  dim3 grid(p.ntiles(), nb), blk(256);
-  size_t sh = (size_t)2 * p.max_feat * GT * sizeof(double);
   p.timer.begin(st, ST_GRAM);
-  if (p.f32)
-    hipLaunchKernelGGL(gram_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.N, p.Npad,
-                       p.D, slot0, write_upper, ~0ull, -1.0);
-  else
-    hipLaunchKernelGGL(gram_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.N, p.Npad,
-                       p.D, slot0, write_upper, ~0ull, -1.0);
+  launch_features(p, st, slot0, nb);  // the table stays valid for this evaluation's trace pass
+  if (p.f32) launch_gram_t<float>(p, st, p.Kbuf32, slot0, nb, write_upper, ~0ull, -1.0);
+  else launch_gram_t<double>(p, st, p.Kbuf, slot0, nb, write_upper, ~0ull, -1.0);
   p.timer.end(st);
   p.timer.work(ST_GRAM, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
@@ -542,14 +706,14 @@ int trace_nwg(const Problem& p) { return (p.ntiles() + TRACE_TPW - 1) / TRACE_TP
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   int nwg = trace_nwg(p);
   dim3 grid(nwg, nb), blk(256);
-  size_t sh = ((size_t)2 * p.max_feat * GT + 4 * p.np_stride) * sizeof(double);
+  size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
   if (p.f32)
-    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf32, p.dalpha,
-                       p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
+    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, p.Kbuf32,
+                       p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg);
   else
-    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dX, p.dtheta, p.Kbuf, p.dalpha,
-                       p.dpart, p.N, p.Npad, p.D, slot0, p.ntiles(), nwg);
+    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, p.Kbuf,
+                       p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg);
   p.timer.end(st);
   p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
