@@ -291,6 +291,10 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_status) hipHostFree(g.h_status);
     if (g.h_spec) hipHostFree(g.h_spec);
   }
+  for (auto& l : p.lanes) {
+    if (l.side) hipStreamDestroy(l.side);
+    for (auto e : l.events) hipEventDestroy(e);
+  }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
                   p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.Kbuf32, p.Mbuf32, p.MTbuf32,
                   p.Pbuf32};

@@ -835,6 +835,42 @@ static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
   return tiles * nb < fill ? 64 : 128;
 }
 
+// ---- side lane: T = S M11 beside the critical path when few fits are in flight ----
+static SideLane* side_lane(Problem& p, hipStream_t st, int nb) {
+  static const int max_nb = [] { const char* e = getenv("WV_SIDE_T"); return e ? atoi(e) : 8; }();
+  if (nb > max_nb || p.Npad < 512) return nullptr;  // full batches fill the GPU from one stream
+  for (auto& l : p.lanes)
+    if (l.main == st) return &l;
+  SideLane l;
+  l.main = st;
+  if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (p.lanes.capacity() < 16) p.lanes.reserve(16);  // (pointers into the vector are held across the recursion)
+  if (p.lanes.size() >= 16) {
+    hipStreamDestroy(l.side);
+    return nullptr;
+  }
+  p.lanes.push_back(l);
+  return &p.lanes.back();
+}
+static hipEvent_t lane_event(SideLane& l) {
+  if (l.next == l.events.size()) {
+    hipEvent_t e;
+    hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    l.events.push_back(e);
+  }
+  return l.events[l.next++];
+}
+// the main stream must not overwrite the S scratch, or read T's output, before the side product is done
+static void lane_join(SideLane* l) {
+  if (l && l->pending) {
+    hipStreamWaitEvent(l->main, l->pending, 0);
+    l->pending = nullptr;
+  }
+}
+
 template <typename R>
 static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
   if (n == NB) {
@@ -855,6 +891,8 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();  // holds S' (h1 x h2): K-strided image of S
   const int64_t sS = p.pbuf_elems();
   fi_node<R>(p, st, slot0, nb, o, h1);
+  SideLane* lane = side_lane(p, st, nb);
+  lane_join(lane);  // an ancestor's T may still be reading the S scratch this node is about to overwrite
   {  // S = A21 * M11'   written transposed;  B(n, k) = M11[n][k] = MT[k][n]  (K-strided)
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = K0 + (o + h1) * Np + o;
@@ -867,12 +905,19 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
+  hipStream_t st_t = st;  // the stream T runs on
+  if (lane) {
+    hipEvent_t s_done = lane_event(*lane);
+    hipEventRecord(s_done, st);
+    hipStreamWaitEvent(lane->side, s_done, 0);
+    st_t = lane->side;
+  }
   {  // A22 -= S S'   with A(m, k) = S'[k][m], B(n, k) = S'[k][n]
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h2;
     a.C = K0 + (o + h1) * Np + (o + h1);
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
-    a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
+    a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.tag = 2;
     p.timer.begin(st, ST_CHOL_TRAIL);
     launch_gemm(st, a, false, false, pick_bn(h2, h2, nb, true));
     p.timer.end(st);
@@ -884,12 +929,18 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.B = M0 + o * Np + o;
     a.C = K0 + (o + h1) * Np + o;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.klo_mode = 2;
-    p.timer.begin(st, ST_TRTRI_A);
-    launch_gemm(st, a, false, false, pick_bn(h2, h1, nb, false));
-    p.timer.end(st);
+    p.timer.begin(st_t, ST_TRTRI_A);
+    launch_gemm(st_t, a, false, false, pick_bn(h2, h1, nb, false));
+    p.timer.end(st_t);
     p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
+  if (lane) {
+    hipEvent_t t_done = lane_event(*lane);
+    hipEventRecord(t_done, lane->side);
+    lane->pending = t_done;  // joined by the next S that overwrites the scratch, at the latest before M21 below
+  }
   fi_node<R>(p, st, slot0, nb, o + h1, h2);
+  lane_join(lane);
   {  // M21 = -M22 * T  (also written transposed into MT);  A(m, k) = M22[m][k] = MT[k][m]
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = MT0 + (o + h1) * Np + (o + h1);
@@ -977,11 +1028,13 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
 }
 
 void factor_value_only(Problem& p, hipStream_t st, int slot0, int nb) {
+  if (SideLane* l = side_lane(p, st, nb)) l->next = 0;
   if (p.f32) fv_node<float>(p, st, slot0, nb, 0, p.Npad);
   else fv_node<double>(p, st, slot0, nb, 0, p.Npad);
 }
 
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb) {
+  if (SideLane* l = side_lane(p, st, nb)) l->next = 0;  // (events of the previous evaluation are all consumed)
   if (p.f32) fi_node<float>(p, st, slot0, nb, 0, p.Npad);
   else fi_node<double>(p, st, slot0, nb, 0, p.Npad);
 }

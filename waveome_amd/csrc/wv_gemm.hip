@@ -46,24 +46,31 @@ struct Tile {
   static constexpr int NLOAD = ROWS / 32;  // double2 loads per thread per chunk
   __device__ static inline int at(int row, int k) { return KCONTIG ? row * LD + k : k * LD + row; }
 
-  // global -> registers. base points at element (row 0, k 0) of the operand for this batch.
-  __device__ static inline void gload(d2 (&reg)[NLOAD], const double* __restrict__ base, int ld,
-                                      int row0, int nrows, int k0, int tid) {
+  // K loop loads: per-thread 32-bit byte offsets from the tile's (row0, k0) element, computed once per tile; a
+  // chunk's loads are then "uniform chunk base + lane offset" (global_load saddr form) - no 64-bit multiply-adds,
+  // no bounds masks and no zero fill per chunk (55 vector instructions per chunk in round 1, each of which delays
+  // the wave's own next MFMA).  Rows past the operand's extent are clamped to its last rows: they only feed C
+  // elements the epilogue masks.  Offsets stay below 128 * ld * 8 bytes, so 32 bits hold for any ld < 2^22.
+  __device__ static inline void goffsets(uint32_t (&off)[NLOAD], int ld, int row0, int nrows, int tid) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      int q = tid + 256 * i;
-      d2 v = {0.0, 0.0};
+      const int q = tid + 256 * i;
       if (KCONTIG) {
-        int row = q >> 3, kp = q & 7;
-        if (row0 + row < nrows)
-          v = *reinterpret_cast<const d2*>(base + (int64_t)(row0 + row) * ld + k0 + 2 * kp);
+        const int row = min(q >> 3, nrows - 1 - row0), kp = q & 7;
+        off[i] = ((uint32_t)row * (uint32_t)ld + 2u * kp) * 8u;
       } else {
-        int k = q / (ROWS / 2), rp = q % (ROWS / 2);
-        if (row0 + 2 * rp < nrows)
-          v = *reinterpret_cast<const d2*>(base + (int64_t)(k0 + k) * ld + row0 + 2 * rp);
+        const int k = q / (ROWS / 2), row = min(2 * (q % (ROWS / 2)), nrows - 2 - row0);
+        off[i] = ((uint32_t)k * (uint32_t)ld + (uint32_t)row) * 8u;
       }
-      reg[i] = v;
     }
+  }
+  // the tile's element (row0, k0): row0 * ld + k0 for K-contiguous operands, k0 * ld + row0 for K-strided ones
+  __device__ static inline const char* chunk_base(const double* __restrict__ base, int ld, int row0, int k0) {
+    return reinterpret_cast<const char*>(base + (KCONTIG ? (int64_t)row0 * ld + k0 : (int64_t)k0 * ld + row0));
+  }
+  __device__ static inline void gload(d2 (&reg)[NLOAD], const char* __restrict__ cbase, const uint32_t (&off)[NLOAD]) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) reg[i] = *reinterpret_cast<const d2*>(cbase + off[i]);
   }
   __device__ static inline void sstore(double* __restrict__ s, const d2 (&reg)[NLOAD], int tid) {
 #pragma unroll
@@ -84,12 +91,13 @@ struct Tile {
 // 1: up to 512 VGPRs, one workgroup per CU, k-steps fully unrolled and software-pipelined).
 // TOUT: 0 = write C; 1 = write only C' (to g.CT, leading dimension g.ldct); 2 = write both.
 // The transposed copy keeps later products on the K-strided (fastest) load path.
-// TAG only gives the K_y^-1 = M'M launch its own symbol so that profilers report it separately.
+// TAG only gives a launch its own symbol so that profilers report it separately: 1 = K_y^-1 = M'M,
+// 2 = the Cholesky trailing update A22 -= S S'.
 template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT, int TAG = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
-  constexpr bool DPPROT = (TAG & 2) != 0;  // experiment: rotated B fragments by DPP instead of three more LDS reads
+  constexpr bool NOLDS = (TAG & 8) != 0;  // timing experiment only: fragments are constants, no LDS reads in the K loop
   constexpr int NJ = BN / 32;  // B fragments per wave
   // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
   // image of half the C tile in the epilogue
@@ -189,9 +197,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   // time (L2 reuse); the others already share their start.
   const int kstep = g.klo_mode ? -KC : KC;
   kb = g.klo_mode ? ke - KC : kb;
+  uint32_t offa[TA::NLOAD], offb[TB::NLOAD];
+  TA::goffsets(offa, g.lda, m0, g.M, tid);
+  TB::goffsets(offb, g.ldb, n0, g.N, tid);
   if (nchunk > 0) {
-    TA::gload(ra, A, g.lda, m0, g.M, kb, tid);
-    TB::gload(rb, B, g.ldb, n0, g.N, kb, tid);
+    TA::gload(ra, TA::chunk_base(A, g.lda, m0, kb), offa);
+    TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kb), offb);
     TA::sstore(sA[0], ra, tid);
     TB::sstore(sB[0], rb, tid);
   }
@@ -199,64 +210,29 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunk && !(g.prio & 4)) {
-      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, tid);
-      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, tid);
+      const int kn = kb + (c + 1) * kstep;
+      TA::gload(ra, TA::chunk_base(A, g.lda, m0, kn), offa);
+      TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
     }
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
-    if (kc0 >= wkb && kc0 < wke && !(g.prio & 8))
+    if (kc0 >= wkb && kc0 < wke && !(g.prio & 8)) {
+      {
 #pragma unroll OCC == 1 ? 4 : 1
-    for (int s = 0; s < KC / 4; ++s) {
-      double af[4];
+        for (int s = 0; s < KC / 4; ++s) {
+          double af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
-      if (DPPROT) {
-        // One LDS read per 16-column group; the three rotated images (column groups shifted by 4 r within the
-        // fragment's 16 lanes) come from DPP row rotations, register to register, issued between the MFMAs of
-        // the previous group (an MFMA occupies the vector issue for a fraction of its 16 cycles).
-        double b0[NJ];
+          for (int i = 0; i < 4; ++i) af[i] = NOLDS ? 1.0 + i + lane * 1e-3 : a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b0[j] = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[0], s * 4 + fk)];
-        auto rot = [](double v, int r) -> double {
-          const int lo = __double2loint(v), hi = __double2hiint(v);
-          if (r == 1) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x12C, 0xF, 0xF, false),
-                                              __builtin_amdgcn_mov_dpp(lo, 0x12C, 0xF, 0xF, false));  // row_ror:12
-          if (r == 2) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, false),
-                                              __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, false));  // row_ror:8
-          return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, false),
-                                  __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, false));              // row_ror:4
-        };
-        double bcur[4], bnext[4];
-        bcur[0] = b0[0];
+          for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int r = 1; r < 4; ++r) bcur[r] = rot(b0[0], r);
+            for (int r = 0; r < 4; ++r) {
+              const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bcur[r], acc[i][j][r], 0, 0, 0);
-            if (j + 1 < NJ && r < 3) bnext[r + 1] = rot(b0[j + 1], r + 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // then the 2 DPP moves of the next rotation
-          }
-          if (j + 1 < NJ) {
-            bcur[0] = b0[j + 1];
-#pragma unroll
-            for (int r = 1; r < 4; ++r) bcur[r] = bnext[r];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double bf = b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+              for (int i = 0; i < 4; ++i)
+                acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+            }
           }
         }
       }
@@ -265,7 +241,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
       TA::sstore(sA[cur ^ 1], ra, tid);
       TB::sstore(sB[cur ^ 1], rb, tid);
     }
-    __syncthreads();
+    if (!(g.prio & 16)) __syncthreads();
   }
 
   // ---- epilogue: C = beta*C + alpha*acc.  D lane 16 i' + 4 blk + j of accumulator (i, j, r)
@@ -379,7 +355,7 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   a.tiles_live = tiles;
   {
     // timing experiments only (results become wrong): 1 = no global C stores, 2 = no epilogue at all,
-    // 4 = no global operand loads inside the K loop, 8 = no MFMAs
+    // 4 = no global operand loads inside the K loop, 8 = no MFMAs, 16 = no barrier in the K loop
     static int dg = -1;
     if (dg < 0) { const char* e = getenv("WV_GEMM_DBG"); dg = e ? atoi(e) : 0; }
     a.prio = dg;
@@ -397,13 +373,15 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     const char* e = getenv("WV_GEMM_OCC");
     occ = (e && atoi(e) == 1) ? 1 : 2;
   }
-  static const bool dpp_rot = [] { const char* e = getenv("WV_GEMM_DPP"); return e && atoi(e) != 0; }();
-  if (a.tag == 1 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
-    if (dpp_rot) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 3>), g, blk, 0, st, a);
-    else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, a);
+  if ((a.prio & 32) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // (timing experiment)
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 8>), g, blk, 0, st, a);
     return;
   }
-  if (dpp_rot && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
+  if (a.tag == 1 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, a);
+    return;
+  }
+  if (a.tag == 2 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // the Cholesky trailing update A22 -= S S'
     hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 2>), g, blk, 0, st, a);
     return;
   }

@@ -194,10 +194,10 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
   const int type = f.type;
   const double c0 = fc[0], var = fc[1];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  auto emit = [&](int a, int c, double val) {
-    if (MODE == 1) k[a][c] += val;
-    else if (MODE == 0) k[a][c] = val;
-    else if (MODE == 3) k[a][c] *= val;
+  auto emit = [&](int a, int c, double scale, double v) {  // factor value = scale * v
+    if (MODE == 1) k[a][c] = fma(scale, v, k[a][c]);
+    else if (MODE == 0) k[a][c] = scale * v;
+    else if (MODE == 3) k[a][c] *= scale * v;
   };
   if (type == WV_K_SE || type == WV_K_M12 || type == WV_K_M32 || type == WV_K_M52) {
     // per-element work given the squared distance q on the factor's columns
@@ -205,7 +205,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
       if (type == WV_K_SE) {
         const double tt = q * c0, e = exp2_64(tt, t.tab);
         if (MODE == 2) { const double we = wo[a][c] * e; s0 += we; s1 = fma(we, tt, s1); }
-        else emit(a, c, var * e);
+        else emit(a, c, var, e);
       } else {
         const double u = sqrt(q) * c0, e = exp2_64(-u, t.tab), z = u * kLn2_64;
         double gg, dl;  // k = var gg, dk/dl = var dl / l
@@ -213,7 +213,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
         else if (type == WV_K_M32) { gg = (1.0 + z) * e; dl = z * z * e; }
         else { const double z23 = z * z * (1.0 / 3.0); gg = (1.0 + z + z23) * e; dl = z23 * (1.0 + z) * e; }
         if (MODE == 2) { s0 = fma(wo[a][c], gg, s0); s1 = fma(wo[a][c], dl, s1); }
-        else emit(a, c, var * gg);
+        else emit(a, c, var, gg);
       }
     };
     if (f.ndims == 1) {
@@ -269,7 +269,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
         s0 += we;
         s1 = fma(we, tt, s1);
         s2 = fma(we, q2, s2);
-      } else emit(a, c, var * e);
+      } else emit(a, c, var, e);
     };
     if (f.ndims == 1) {
       const int ss = slots[f.slot0], sc = slots[f.slot0 + 1], sr = slots[f.slot0 + 2];
@@ -363,7 +363,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
         for (int c = 0; c < 4; ++c) {
           const double base = var * q[a][c] + off, pm1 = ipow(base, deg - 1);
           if (MODE == 2) { const double dk = deg * pm1 * wo[a][c]; s0 = fma(dk, q[a][c], s0); s1 += dk; }
-          else emit(a, c, pm1 * base);
+          else emit(a, c, pm1, base);
         }
     } else {  // Lin, Categorical: k = var q, dk/dvar = q
 #pragma unroll
@@ -371,7 +371,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (MODE == 2) s0 = fma(wo[a][c], q[a][c], s0);
-          else emit(a, c, var * q[a][c]);
+          else emit(a, c, var, q[a][c]);
         }
     }
   } else if (type == WV_K_CONST) {
@@ -380,13 +380,13 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (MODE == 2) s0 += wo[a][c];
-        else emit(a, c, var);
+        else emit(a, c, var, 1.0);
       }
   } else {  // WV_K_EMPTY
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) emit(a, c, 0.0);
+      for (int c = 0; c < 4; ++c) emit(a, c, 0.0, 0.0);
   }
   if (MODE == 2) { s[0] = s0; s[1] = s1; s[2] = s2; }
 }
