@@ -374,7 +374,9 @@ def main():
                        "iterations_per_fit": {"min": int(table[:, 2].min()), "mean": float(table[:, 2].mean())},
                        "status_counts": {str(int(k)): int(v) for k, v in
                                          zip(*np.unique(table[:, 4], return_counts=True))}},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_f64_kernel<false, false, 128, 2, 0, 1> ({DOMINANT_STAGE})",
+            "roofline": {"bound": "mfma",
+                         "kernel": f"gemm_f64_kernel<false, false, 128, 2, 0, 1> + its diagonal-tile launch <..., 0, 5> "
+                                   f"({DOMINANT_STAGE}: K_y^-1 = M'M, one pair of launches per evaluation round)",
                          "achieved": ach, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

@@ -87,6 +87,31 @@ struct Tile {
   }
 };
 
+// One K chunk (4 k-steps) for one wave of a DIAGONAL tile of a square lower-only product (see TRIOPT in the kernel).
+//   LOWER: the wave owns a diagonal 64 x 64 block and computes only accumulator blocks i >= j (40 of 64 MFMAs);
+//   else : the wave owns 32 columns (column groups 0, 1 relative to bcol) of the full block below (32 MFMAs).
+// Compile-time masks only - a wave-uniform runtime mask (scalar branches between the MFMAs) ran 70 % slower.
+template <bool LOWER, typename TA, typename TB, int NJ>
+__device__ inline void mma_chunk_diag(double (&acc)[4][NJ][4], const double* __restrict__ a_s,
+                                      const double* __restrict__ b_s, int arow, int bcol, const int (&brot)[4], int fr,
+                                      int fk) {
+  for (int s = 0; s < KC / 4; ++s) {
+    double af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = a_s[TA::at(arow + i * 16 + fr, s * 4 + fk)];
+#pragma unroll
+    for (int j = 0; j < (LOWER ? NJ : NJ / 2); ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double bf = b_s[TB::at(bcol + j * 16 + brot[r], s * 4 + fk)];
+#pragma unroll
+        for (int i = (LOWER ? j : 0); i < 4; ++i)
+          acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+      }
+    }
+  }
+}
+
 // OCC = waves per SIMD the register allocator may assume (2: <= 256 VGPRs, two workgroups per CU;
 // 1: up to 512 VGPRs, one workgroup per CU, k-steps fully unrolled and software-pipelined).
 // TOUT: 0 = write C; 1 = write only C' (to g.CT, leading dimension g.ldct); 2 = write both.
@@ -133,14 +158,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   if (g.tri) {
     // (rotating lower-only products or row-dependent lengths the same way measured no gain)
     if (g.rot_tri > 0) tile = (tile + ((5 * (b >> 3) + (b & 7)) & 31)) % tiles;
-    tm = 0;
-    for (;;) {
-      const int cnt = min(g.tiles_n, max(0, (tm * BM + BM - 1 - g.tri_off) / BN + 1));
-      if (tile < cnt) break;
-      tile -= cnt;
-      ++tm;
+    if (g.tri == 2) {  // the diagonal tiles only (square tiles, tri_off == 0)
+      tm = tile;
+      tn = tile;
+    } else {
+      tm = 0;
+      for (;;) {
+        int cnt = min(g.tiles_n, max(0, (tm * BM + BM - 1 - g.tri_off) / BN + 1));
+        if (g.tri == 3) cnt = min(cnt, tm);  // ... or all lower tiles but those
+        if (tile < cnt) break;
+        tile -= cnt;
+        ++tm;
+      }
+      tn = tile;
     }
-    tn = tile;
   } else {
     tm = tile / g.tiles_n;
     tn = tile % g.tiles_n;
@@ -177,18 +208,34 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
+  // TRIOPT (TAG bit 2): this instantiation is launched on the DIAGONAL tiles of a square lower-only product only
+  // (g.tri == 2).  Of such a tile's four 64 x 64 blocks three are needed, two of them only in their lower
+  // triangle, yet in the general kernel the tile takes as long as a full one (its time is set by the wave that
+  // owns the full block).  Here the two diagonal waves skip the 16 x 16 accumulator blocks above the diagonal
+  // (40 of 64 MFMAs per k-step) and the wave whose own block lies above the diagonal takes over the right 32
+  // columns of the full block (32 MFMAs each): no partial sums to merge.  (ewm, ewn) = the 64 x 64 block a wave
+  // works on, ecol = its first column inside that block, half = it owns 32 columns only.
+  constexpr bool TRIOPT = (TAG & 4) != 0 && BN == 128 && TOUT == 0;
+  int ewm = wm, ewn = wn, ecol = 0;
+  bool half = false;
+  if (TRIOPT && wm != wn) {
+    half = true;
+    ecol = wm == 1 ? 0 : 32;
+    ewm = 1;
+    ewn = 0;
+  }
   // Per-wave contraction range at 64-row / (BN/2)-column granularity: a wave whose 64 x BN/2
   // sub-tile needs fewer chunks (triangular operand) or none (above the diagonal of a lower-only
   // product) skips the MFMAs - it still loads and synchronises - and its SIMD time goes to the
   // co-resident workgroup.
   int wkb = kb, wke = ke;
   {
-    const int wr = m0 + wm * 64, wc = n0 + wn * (BN / 2);
+    const int wr = m0 + ewm * 64, wc = n0 + ewn * (BN / 2);
     if (g.klo_mode == 1) wkb = max(wkb, wr + g.koff);
     if (g.klo_mode == 2) wkb = max(wkb, wc + g.koff);
     if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
     if (g.khi_mode == 2) wke = min(wke, wc + BN / 2 + g.koff);
-    if (g.tri && wc + g.tri_off > wr + 63) wke = wkb;  // nothing to do
+    if (g.tri && !TRIOPT && wc + g.tri_off > wr + 63) wke = wkb;  // nothing to do
   }
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb) / KC;
@@ -218,7 +265,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
     const double* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
     if (kc0 >= wkb && kc0 < wke && !(g.prio & 8)) {
-      {
+      if constexpr (TRIOPT) {
+        if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
+        else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * (BN / 2), brot, fr, fk);
+      } else {
 #pragma unroll OCC == 1 ? 4 : 1
         for (int s = 0; s < KC / 4; ++s) {
           double af[4];
@@ -276,21 +326,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
         cv[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const d2*>(C + (int64_t)m * g.ldc + n) : d2{0.0, 0.0};
       }
     }
-    if (wm == h) {
+    if (ewm == h) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
+          // (TRIOPT) a wave that owns 32 columns writes its two column groups; blocks a diagonal wave skipped hold
+          // zeros: alpha * 0 leaves beta * C, and nobody reads above the diagonal of a lower-only product
+          if (TRIOPT && half && j >= NJ / 2) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            smem[(i * 16 + 4 * fblk + fk) * LDC + wn * (BN / 2) + j * 16 + brot[r]] = alpha * acc[i][j][r];
+            smem[(i * 16 + 4 * fblk + fk) * LDC + ewn * (BN / 2) + ecol + j * 16 + brot[r]] = alpha * acc[i][j][r];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NROWIT; ++it) {
       const int q = tid + 256 * it, row = q / PAIRS, cp = q % PAIRS;
       const int m = m0 + 64 * h + row, n = n0 + 2 * cp;
-      if (m < g.M && n < g.N) {
+      // (TRIOPT: the upper right 64 x 64 block of a diagonal tile is computed by nobody, its staging words are stale)
+      if (m < g.M && n < g.N && !(TRIOPT && h == 0 && 2 * cp >= BN / 2)) {
         d2 v = *reinterpret_cast<const d2*>(smem + row * LDC + 2 * cp);
         if (beta != 0.0) {
           v.x += beta * cv[it].x;
@@ -377,12 +432,28 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 8>), g, blk, 0, st, a);
     return;
   }
-  if (a.tag == 1 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, a);
-    return;
-  }
-  if (a.tag == 2 && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // the Cholesky trailing update A22 -= S S'
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 2>), g, blk, 0, st, a);
+  if ((a.tag == 1 || a.tag == 2) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {
+    // K_y^-1 = M'M (tag 1) and the Cholesky trailing update A22 -= S S' (tag 2): square lower-only products.
+    // Their diagonal tiles go to a second launch whose waves share the three needed 64 x 64 blocks evenly
+    // (TRIOPT in the kernel): trailing update -6.5 %, M'M -2 % at N = 2048.  WV_TRI_SPLIT=0: one launch.
+    static const bool split = [] { const char* e = getenv("WV_TRI_SPLIT"); return e ? atoi(e) != 0 : true; }();
+    const bool can_split = split && a.tri == 1 && a.tri_off == 0 && a.M == a.N && a.tiles_m > 1 && a.M % BM == 0;
+    GemmArgs o = a;
+    if (can_split) {
+      o.tri = 3;
+      o.tiles_live = tiles - a.tiles_m;
+      g = dim3((a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * o.tiles_live : a.nbatch * o.tiles_live);
+    }
+    if (a.tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 1>), g, blk, 0, st, o);
+    else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 2>), g, blk, 0, st, o);
+    if (can_split) {
+      GemmArgs d = a;
+      d.tri = 2;
+      d.tiles_live = a.tiles_m;
+      const dim3 gd((a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * d.tiles_live : a.nbatch * d.tiles_live);
+      if (a.tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 5>), gd, blk, 0, st, d);
+      else hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 6>), gd, blk, 0, st, d);
+    }
     return;
   }
   if (a.tout != 0) {
