@@ -142,16 +142,18 @@ def cpu_baseline(X, Y, evals_per_fit, seconds_budget=24.0):
 def pmc_traffic(fits_per_launch):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process, so
     the figure comes from the committed rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, corrected as
-    MI355X_MICROARCH.md prescribes; profiles/r01_traffic.json) of the same kernel on the same workload, scaled
-    to the fits one launch covers here.  None when the summary is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    try:
-        with open(path) as fh:
-            k = json.load(fh)["kernels"]["lauum_gemm"]
-    except (OSError, KeyError, ValueError):
-        return None, None
-    per_fit = (k["read_bytes"] + k["write_bytes"]) / k["fits_per_launch"]
-    return per_fit * fits_per_launch, "profiles/r01_traffic.json (offline rocprofv3 PMC passes, per fit x fits per launch)"
+    MI355X_MICROARCH.md prescribes; profiles/r02_traffic.json, made by tools/make_traffic_json.py) of the same
+    kernel on the same workload, scaled to the fits one launch covers here.  None when the summary is absent."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as fh:
+                k = json.load(fh)["kernels"]["lauum_gemm"]
+        except (OSError, KeyError, ValueError):
+            continue
+        per_fit = (k["read_bytes"] + k["write_bytes"]) / k["fits_per_launch"]
+        return per_fit * fits_per_launch, f"profiles/{name} (offline rocprofv3 PMC passes, per fit x fits per launch)"
+    return None, None
 
 
 def bench_c5(args):
