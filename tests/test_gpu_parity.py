@@ -69,12 +69,10 @@ ALL_KERNELS = {
 
 # ---------------------------------------------------------------- MFMA GEMM kernel
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("bn", [128, 64, 256])  # 256 = the LDS-DMA 256x128 kernel
+@pytest.mark.parametrize("bn", [128, 64])
 def test_mfma_gemm_variants(ctx, a_kc, b_kc, bn):
     rng = np.random.default_rng(1)
     nb, M, N, Kd = 9, 192, 320, 80  # ragged against the 128-wide tiles; 9 batches exercises the XCD map
-    if bn == 256:
-        M, N, Kd = 448, 320, 112  # ragged against 256 x 128; 7 chunks exercises the 3-stage ring
     # exact-integer, asymmetric operands: any lane-map or transpose slip shows up exactly
     A = rng.integers(-8, 9, size=(nb, M, Kd)).astype(float)
     B = rng.integers(-8, 9, size=(nb, N, Kd)).astype(float)

@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0,'.')
 from waveome_amd.engine import Context
 c=Context(0)
-print("bn 128 = v1 (forced via WV_GEMM2_MIN=0 env not set here -> auto), bn 256 = v2; mode 0 full 1 lauum 2 syrk 3 trimmed")
+print("mode 0 full, 1 lauum-like (lower tiles, contraction from the tile row), 2 syrk-like (lower tiles, beta = 1), 3 trimmed k < n0 + BN")
 for (M,N,K,nb,akc,bkc,mode) in [(2048,2048,2048,32,0,0,0),(2048,2048,2048,32,0,0,1),(2048,2048,2048,128,0,0,1),
                                (1024,1024,1024,128,1,1,0),(1024,1024,1024,128,1,1,2),(1024,1024,1024,128,1,1,3),(1024,1024,1024,128,1,0,0),
                                (512,512,512,128,1,1,0),(512,512,512,128,1,1,2),(256,256,256,128,1,1,0)]:

@@ -352,6 +352,7 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
     p.max_feat = std::max(p.max_feat, (int)hspecs[si].n_feat);
     p.max_fact = std::max(p.max_fact, (int)hspecs[si].n_factors);
     p.max_red = std::max(p.max_red, (int)hspecs[si].n_red);
+    for (int fi = 0; fi < hspecs[si].n_factors; ++fi) p.any_multidim |= hspecs[si].factors[fi].ndims > 1;
   }
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
   p.spec = p.specs[0];

@@ -40,6 +40,8 @@ __device__ inline float rsq(float x) { return rsqrtf(x); }
 
 // Triangular-inverse combine step of size H inside the 64x64 block: for every 2H diagonal block
 // X21 = -X22 (L21 X11), all operands in LDS.
+// T is a compact scratch of NB/2 * H <= 1024 entries: entry (pair blk, row i, column c) at (blk * H + i) * H + c.
+constexpr int INV_SCRATCH = NB * NB / 4;
 template <int H, typename R>
 __device__ inline void inv_level(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
   constexpr int NPAIR = NB / (2 * H);
@@ -49,14 +51,14 @@ __device__ inline void inv_level(const R* __restrict__ L, R* __restrict__ X, R* 
     R s = 0;
 #pragma unroll 8
     for (int k = c; k < H; ++k) s += L[(o + H + i) * DS + o + k] * X[(o + k) * DS + o + c];
-    T[(o + H + i) * DS + o + c] = s;
+    T[q] = s;
   }
   __syncthreads();
   for (int q = tid; q < NPAIR * PER; q += 256) {
     const int blk = q / PER, e = q % PER, i = e / H, c = e % H, o = blk * 2 * H;
     R s = 0;
 #pragma unroll 8
-    for (int k = 0; k <= i; ++k) s += X[(o + H + i) * DS + o + H + k] * T[(o + H + k) * DS + o + c];
+    for (int k = 0; k <= i; ++k) s += X[(o + H + i) * DS + o + H + k] * T[(blk * H + k) * H + c];
     X[(o + H + i) * DS + o + c] = -s;
   }
   __syncthreads();
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(R* __restrict__ Kall, R
                                                          int64_t Npad, int nblk, int slot0, int j0) {
   __shared__ R L[NB * DS];
   __shared__ R X[NB * DS];
-  __shared__ R T[NB * DS];
+  __shared__ R T[INV_SCRATCH];
   __shared__ R colbuf[2][NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
@@ -264,9 +266,11 @@ template <typename R>
 __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* __restrict__ Mall, R* __restrict__ MTall,
                                                        double* __restrict__ logdet, int32_t* __restrict__ status,
                                                        int64_t Npad, int nblk, int slot0, int o) {
+  // LDS: L and X (64 x 65 each) + the compact inversion scratch: 76 KB in float64, so TWO workgroups share a CU
+  // (round 1 kept a third 64 x 65 array, 100 KB: one workgroup per CU, two passes over a 512-fit batch).
   __shared__ R L[NB * DS];
   __shared__ R X[NB * DS];
-  __shared__ R T[NB * DS];
+  __shared__ R T[INV_SCRATCH];
   __shared__ R colbuf[2][NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
@@ -316,13 +320,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
   invert64<R>(L, X, T, tid);  // X = M11
   write_inverse_block(o1, o1);
 
-  // ---- S = A21 M11'  (A21 staged in T; M11 lower: k <= column) ----
+  // ---- S = A21 M11'  (A21 staged in L - L11 is dead once M11 and its log-det exist; M11 lower: k <= column) ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     R v[4];
     ld4(K + (o2 + 4 * ty + r) * Npad + o1 + 4 * tx, v);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) T[(4 * ty + r) * DS + 4 * tx + c] = v[c];
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = v[c];
   }
   __syncthreads();
   R sacc[4][4];
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
   for (int k = 0; k < 4 * tx + 4; ++k) {
     R ar[4], mc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ar[r] = T[(4 * ty + r) * DS + k];
+    for (int r = 0; r < 4; ++r) ar[r] = L[(4 * ty + r) * DS + k];
 #pragma unroll
     for (int c = 0; c < 4; ++c) mc[c] = X[(4 * tx + c) * DS + k];
 #pragma unroll
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
 #pragma unroll
       for (int c = 0; c < 4; ++c) sacc[r][c] += ar[r] * mc[c];
   }
-  __syncthreads();  // every read of L (log-det, inversion) and of T (A21) is done
+  __syncthreads();  // every read of L (A21) is done
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -382,11 +386,11 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
   write_inverse_block(o2, o2);
   if (tid == 0 && bad) status[b] = 1;
 
-  // ---- M21 = -M22 T2  (T2 staged in T; M22 lower: k <= row) ----
+  // ---- M21 = -M22 T2  (T2 staged in L - L22 is dead after the inversion; M22 lower: k <= row) ----
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) T[(4 * ty + r) * DS + 4 * tx + c] = t2[r][c];
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = t2[r][c];
   __syncthreads();
   R macc[4][4];
 #pragma unroll
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) mr[r] = X[(4 * ty + r) * DS + k];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) tc[c] = T[k * DS + 4 * tx + c];
+    for (int c = 0; c < 4; ++c) tc[c] = L[k * DS + 4 * tx + c];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll

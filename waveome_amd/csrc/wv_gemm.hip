@@ -373,17 +373,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   }
 }
 
-void launch_gemm2(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc);
-
 void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int bn) {
-  // large outputs go to the 256 x 128 LDS-DMA kernel (wv_gemm2.hip); bn == 256 forces it
-  static int v2_min = -1;
-  if (v2_min < 0) {
-    const char* e = getenv("WV_GEMM2_MIN");
-    v2_min = e ? atoi(e) : 0;  // off by default: no faster on the triangular forms
-  }
-  if (a_in.tout == 0 && (bn == 256 || (bn == 128 && v2_min > 0 && a_in.M >= v2_min && a_in.N >= 128))) {
-    launch_gemm2(st, a_in, a_kc, b_kc);
+  if (bn != 64 && bn != 128) {
+    fail_launch("launch_gemm: tile width must be 64 or 128");
     return;
   }
   GemmArgs a = a_in;

@@ -24,6 +24,8 @@
 //     constants once per tile instead of per element.
 // Thread layout: 256 threads as 16 x 16, each owning rows ty + 16a (a < 4) and 4 contiguous
 // columns 4 tx .. 4 tx + 3 (32-byte row segments -> 512 B contiguous per 16 threads).
+#include <cstdlib>
+
 #include "wv_device.hpp"
 
 namespace wv {
@@ -187,7 +189,7 @@ __device__ inline void stage_exp_table(double* tab, int tid) {
 // (4 in flight per wave are enough beside 2-3 resident waves, 16 cost ~60 more VGPRs and spill).
 #define WV_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int MODE>
+template <int MODE, bool MULTI = true>
 __device__ inline void factor_tile(const DevFactor& f, const double* __restrict__ fc,
                                    const int16_t* __restrict__ slots, const TileCtx& t, double (&k)[4][4],
                                    const double (&wo)[4][4], double (&s)[3]) {
@@ -216,7 +218,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
         else emit(a, c, var, gg);
       }
     };
-    if (f.ndims == 1) {
+    if (!MULTI || f.ndims == 1) {
       const int sl = slots[f.slot0];
       double xj[4];
 #pragma unroll
@@ -271,7 +273,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
         s2 = fma(we, q2, s2);
       } else emit(a, c, var, e);
     };
-    if (f.ndims == 1) {
+    if (!MULTI || f.ndims == 1) {
       const int ss = slots[f.slot0], sc = slots[f.slot0 + 1], sr = slots[f.slot0 + 2];
       double sj[4], cj[4], xj[4];
 #pragma unroll
@@ -556,8 +558,11 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // reduced over its quad in registers and added to the slot's 64 per-quad accumulators in LDS (ds_add_f64, fire
 // and forget); one full reduction per slot happens at the very end of the workgroup instead of one per slot, factor
 // and tile.
-template <typename R>
-__global__ __launch_bounds__(256, 2) void trace_kernel(const DevSpec* __restrict__ specs,
+// MULTI = false: every factor of every structure acts on ONE column (what full_kernel_build produces): the paths that
+// keep 4 x 4 distance arrays are not instantiated, 186 instead of 230 VGPRs, and the kernel is held to 168 (3 waves per
+// SIMD instead of 2; 11 VGPRs spill) - the pass is latency-bound, not issue-bound (section 4.0 of DESIGN.md).
+template <typename R, bool MULTI>
+__global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ F, const double* __restrict__ FC,
                                                     const double* __restrict__ theta_all,
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void trace_kernel(const DevSpec* __restrict
         if (fg.trainable == 0) continue;
         double s[3], unused[4][4];
         if (f1 - f0 == 1) {
-          factor_tile<2>(fg, t.fc + 4 * g, slots, t, unused, w, s);
+          factor_tile<2, MULTI>(fg, t.fc + 4 * g, slots, t, unused, w, s);
         } else {
           double wo[4][4];
 #pragma unroll
@@ -639,8 +644,8 @@ __global__ __launch_bounds__(256, 2) void trace_kernel(const DevSpec* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) wo[a][c] = w[a][c];
           for (int f = f0; f < f1; ++f)
-            if (f != g) factor_tile<3>(sp->factors[f], t.fc + 4 * f, slots, t, wo, wo, s);
-          factor_tile<2>(fg, t.fc + 4 * g, slots, t, unused, wo, s);
+            if (f != g) factor_tile<3, MULTI>(sp->factors[f], t.fc + 4 * f, slots, t, wo, wo, s);
+          factor_tile<2, MULTI>(fg, t.fc + 4 * g, slots, t, unused, wo, s);
         }
         contribute(fg.sbase, s[0]);
         if (fg.nsum > 1) contribute(fg.sbase + 1, s[1]);
@@ -708,12 +713,19 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   dim3 grid(nwg, nb), blk(256);
   size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
-  if (p.f32)
-    hipLaunchKernelGGL(trace_kernel<float>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, p.Kbuf32,
-                       p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg);
-  else
-    hipLaunchKernelGGL(trace_kernel<double>, grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, p.Kbuf,
-                       p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg);
+#define WV_TRACE_LAUNCH(RT, MU, KBUF)                                                                              \
+  hipLaunchKernelGGL((trace_kernel<RT, MU>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
+                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg)
+  static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
+  const bool multi = p.any_multidim || force_multi;
+  if (p.f32) {
+    if (multi) WV_TRACE_LAUNCH(float, true, p.Kbuf32);
+    else WV_TRACE_LAUNCH(float, false, p.Kbuf32);
+  } else {
+    if (multi) WV_TRACE_LAUNCH(double, true, p.Kbuf);
+    else WV_TRACE_LAUNCH(double, false, p.Kbuf);
+  }
+#undef WV_TRACE_LAUNCH
   p.timer.end(st);
   p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
