@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WV_ABI_VERSION 1
+#define WV_ABI_VERSION 2
 
 typedef struct wv_ctx wv_ctx;
 typedef struct wv_problem wv_problem;
@@ -236,6 +236,44 @@ int32_t wv_fit_multi(wv_problem* prob, const int32_t* col_idx, const int32_t* sp
                      const wv_lbfgs_opts* opts, const double* prior_scale, int32_t u_stride,
                      double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
                      int32_t* n_eval_out, int32_t* status_out);
+
+/* ---- a work queue that accepts tasks while it runs ------------------------------------------------------------
+ * The reference's stepwise kernel search runs one Ray task per output column, each walking its own search tree
+ * and calling kernel_test once per candidate (waveome/model_search.py:1200-1222, 2987-3273): columns never wait
+ * for each other.  wv_fit_multi takes a FIXED task list, so a caller pooling the candidates of all columns has to
+ * advance them level by level.  wv_queue_* expose the same work queue incrementally: submit (column, structure,
+ * start point) tasks at any time, call wv_queue_advance to run one scheduling step (one batched evaluation round of
+ * one batch group), fetch finished fits, submit what they unlock.  New kernel structures are added to the problem
+ * with wv_problem_add_spec; the problem must have been created with room for them (wv_problem_create_ex).
+ * Fits are bit-identical to wv_fit_multi's: a batch slot's arithmetic does not depend on its neighbours.
+ * One queue per problem at a time; not thread-safe (like the problem itself). */
+typedef struct wv_queue wv_queue;
+typedef struct {
+  int32_t max_specs;   /* kernel structures the problem can hold */
+  int32_t max_params;  /* parameters of one structure (kernel parameters + noise + mean) */
+  int32_t max_feat;    /* staged feature slots of one structure (<= 64) */
+  int32_t max_factors; /* kernel factors of one structure (<= 128) */
+  int32_t max_red;     /* gradient sums of one structure: 1-3 per trainable factor, + 1 */
+} wv_problem_caps;
+/* wv_problem_create_multi with explicit capacities (each at least what `specs` need; caps = NULL: exactly that). */
+int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
+                             const wv_kernel_spec* const* specs, int32_t n_specs, const wv_problem_caps* caps,
+                             int32_t max_batch, int32_t x_is_device, int32_t y_is_device, wv_problem** out);
+/* Adds a structure to a problem; *index_out is its spec_idx.  WV_E_UNSUPPORTED when it exceeds a capacity. */
+int32_t wv_problem_add_spec(wv_problem* prob, const wv_kernel_spec* spec, int32_t* index_out);
+int32_t wv_queue_create(wv_problem* prob, const wv_lbfgs_opts* opts, wv_queue** out);
+/* theta_u0 is n x u_stride (a task uses the first n_trainable of its row); prior_scale may be NULL; tags are the
+ * caller's handles, returned by wv_queue_fetch. */
+int32_t wv_queue_submit(wv_queue* q, int32_t n, const int32_t* col_idx, const int32_t* spec_idx,
+                        const double* prior_scale, int32_t u_stride, const double* theta_u0, const int64_t* tags);
+/* One scheduling step (returns at once when nothing is queued or in flight).  n_done_out: finished fits waiting to
+ * be fetched; n_in_system_out: tasks queued or being fitted. */
+int32_t wv_queue_advance(wv_queue* q, int32_t* n_done_out, int32_t* n_in_system_out);
+/* Up to cap finished fits, oldest first; theta_u_out is cap x u_stride. */
+int32_t wv_queue_fetch(wv_queue* q, int32_t cap, int32_t u_stride, int64_t* tags_out, double* theta_u_out,
+                       double* loss_out, double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out,
+                       int32_t* status_out, int32_t* n_out);
+void wv_queue_destroy(wv_queue* q);
 
 /* Posterior prediction for ONE task at constrained table theta: mean and variance of f (and of
  * y = f + noise when include_noise != 0).  Replaces predict_f / predict_y

@@ -755,6 +755,69 @@ def test_multi_structure_fit_with_priors_and_a_failing_task(ctx):
         assert abs(want - r["loss"][t]) <= 1e-9 * max(1.0, abs(want))
 
 
+def test_work_queue_fed_incrementally_equals_fit_multi(ctx):
+    """wv_queue_* on a growable problem (wv_problem_create_ex / wv_problem_add_spec): tasks submitted while others
+    are being fitted, a structure added mid-run - every fit equals wv_fit_multi's on the same task, bit for bit."""
+    from waveome_amd import _lib as L
+    from waveome_amd.engine import FitQueue, Problem, lbfgs_opts
+
+    X, Y = _data(43, 130, D=4, P=4)
+    specs = [ModelSpec(K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])]), 4, K.GaussianLikelihood(),
+                       K.ConstantMean()),
+             ModelSpec(K.Product([K.Categorical(active_dims=[3]), K.Matern32(active_dims=[0])]), 4, K.GaussianLikelihood(),
+                       K.ConstantMean()),
+             ModelSpec(K.Periodic(K.SquaredExponential(active_dims=[2])), 4, K.GaussianLikelihood(), K.ConstantMean())]
+    opts = lbfgs_opts(maxiter=25)
+    cols = np.array([0, 1, 2, 3, 0, 2, 1, 3, 2], dtype=np.int32)
+    sidx = np.array([0, 0, 1, 1, 2, 2, 0, 2, 1], dtype=np.int32)
+    width = 8
+    U0 = np.zeros((len(cols), width))
+    for t, si in enumerate(sidx):
+        U0[t, :specs[si].n_trainable] = specs[si].unconstrain() + 0.05 * t
+    caps = {"max_specs": 3, "max_params": 8, "max_feat": 6, "max_factors": 4, "max_red": 8}
+    ref_prob = Problem(ctx, X, Y, specs, max_batch=3, capacity=caps)  # (same table strides and kernel variants)
+    ref = ref_prob.fit_multi(cols, sidx, U0, opts)
+    ref_prob.close()
+
+    prob = Problem(ctx, X, Y, [specs[0]], max_batch=3, capacity=caps)
+    assert prob.add_spec(specs[1]) == 1
+    q = FitQueue(prob, opts, width=width)
+    first = [0, 1, 2, 3, 6]                       # structures 0 and 1
+    q.submit(cols[first], sidx[first], U0[first], tags=np.array(first))
+    got = {}
+    for _ in range(4):                            # a few rounds in: add the third structure and its tasks
+        q.advance()
+    assert prob.add_spec(specs[2]) == 2
+    later = [4, 5, 7, 8]
+    q.submit(cols[later], sidx[later], U0[later], tags=np.array(later))
+    with pytest.raises(L.WaveomeAmdError):        # the structure table is full now
+        prob.add_spec(specs[0])
+    steps = 0
+    while q.in_system > 0 or q.done > 0:
+        done, _ = q.advance()
+        if done:
+            r = q.fetch()
+            for j, tg in enumerate(r["tag"]):
+                got[int(tg)] = {k: r[k][j] for k in ("u", "loss", "lml", "nit", "nfev", "status")}
+        steps += 1
+        assert steps < 10000
+    q.close()
+    prob.close()
+    assert sorted(got) == list(range(len(cols)))
+    for t in range(len(cols)):
+        nt = specs[sidx[t]].n_trainable
+        assert got[t]["loss"] == ref["loss"][t] and got[t]["lml"] == ref["lml"][t]
+        assert got[t]["nit"] == ref["nit"][t] and got[t]["nfev"] == ref["nfev"][t] and got[t]["status"] == ref["status"][t]
+        np.testing.assert_array_equal(got[t]["u"][:nt], ref["u"][t, :nt])
+    # a structure beyond a capacity is refused, not truncated
+    small = Problem(ctx, X, Y, [specs[0]], max_batch=2, capacity={"max_specs": 4, "max_params": 5, "max_feat": 2,
+                                                                  "max_factors": 2, "max_red": 4})
+    with pytest.raises(L.WaveomeAmdError):
+        small.add_spec(ModelSpec(K.Sum([K.Periodic(K.SquaredExponential(active_dims=[d])) for d in range(3)]), 4,
+                                 K.GaussianLikelihood(), K.ConstantMean()))
+    small.close()
+
+
 def _random_tree(rng, depth):
     kinds = ["se", "m12", "m32", "m52", "per", "lin", "poly", "cat", "const"]
     if depth == 0 or rng.random() < 0.3:

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and headers disagree"
-    assert lib.wv_abi_version() == 1
+    assert lib.wv_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly_not_silently(lib):

@@ -8,6 +8,8 @@ import copy
 import sys
 from pathlib import Path
 
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -204,6 +206,60 @@ def test_oracle_scored_search_recovers_structure():
     assert res[2]["best_model"] == "constant"
 
 
+class _DelayedOracleSession:
+    """Stand-in for kernel_search._SearchSession on the CPU: fits come from the oracle scorer, but a request is
+    answered only a few `pump` calls later and in scrambled order - what the GPU work queue does to the driver."""
+
+    def __init__(self, scorer, seed=0):
+        self.sc, self.rng, self.inflight = scorer, np.random.default_rng(seed), []
+        self.pumps = 0
+
+    def request(self, col, kernel, callback):
+        spec = ModelSpec(kernel, self.sc.X.shape[1], K.GaussianLikelihood(), K.ConstantMean())
+        if (col, ks.structure_signature(spec)) in self.sc.cache:
+            callback(self.sc([(col, kernel)])[0])
+            return
+        self.inflight.append([int(self.rng.integers(1, 5)), col, kernel, callback])
+
+    def busy(self):
+        return bool(self.inflight)
+
+    def pump(self):
+        self.pumps += 1
+        self.rng.shuffle(self.inflight)
+        due = [t for t in self.inflight if t[0] <= 1]
+        self.inflight = [[t[0] - 1] + t[1:] for t in self.inflight if t[0] > 1]
+        for _, col, kernel, cb in due:
+            cb(self.sc([(col, kernel)])[0])
+
+    def close(self):
+        pass
+
+
+def test_unsynchronised_search_equals_lock_step_search():
+    """run_searches_async: columns advance whenever THEIR candidates are scored; same fits, so the same trees."""
+    from waveome_amd.model_search import GPSearch
+
+    X, Y = search_data()
+    gps = GPSearch(X, Y, categorical_vars=["grp"])
+    Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+    kl = [K.SquaredExponential(), K.Lin()]
+    scorer = OracleScorer(Xn, Yn)
+    ref = ks.run_searches(range(3), 3, kl, scorer, cat_vars=[2], max_depth=3, keep_only_best=False)
+    fits_lock_step = scorer.n_fits
+    scorer2 = OracleScorer(Xn, Yn)
+    session = _DelayedOracleSession(scorer2, seed=5)
+    got = ks.run_searches_async(range(3), 3, kl, scorer2, cat_vars=[2], max_depth=3, keep_only_best=False,
+                                session=session)
+    assert session.pumps > 3 and scorer2.n_fits == fits_lock_step
+    for c in range(3):
+        assert got[c]["best_model"] == ref[c]["best_model"]
+        assert set(got[c]["models"]) == set(ref[c]["models"]) and got[c]["edges"] == ref[c]["edges"]
+        for name in ref[c]["models"]:
+            assert got[c]["models"][name]["bic"] == ref[c]["models"][name]["bic"]
+            assert got[c]["models"][name]["parent"] == ref[c]["models"][name]["parent"]
+
+
 @pytest.mark.gpu
 def test_gpu_search_matches_oracle_scored_search():
     from waveome_amd.model_search import GPSearch
@@ -228,6 +284,18 @@ def test_gpu_search_matches_oracle_scored_search():
         assert abs(m.training_loss() - got["models"][got["best_model"]]["fit"]["loss"]) < 1e-6
         assert len(got["var_exp"]) == (len(m.kernel.kernels) if m.kernel.name == "sum" else 1) + 1
     assert gps.search_stats["fits"] > 30
+    # the default driver is the unsynchronised one; the level-by-level driver must give the same search, bit for bit
+    os.environ["WV_SEARCH_ASYNC"] = "0"
+    try:
+        gps2 = GPSearch(X, Y, categorical_vars=["grp"])
+        gps2.run_search(kernels=kl, max_depth=3, keep_only_best=False)
+    finally:
+        del os.environ["WV_SEARCH_ASYNC"]
+    for feat in gps.out_names:
+        a, b = gps.search_info[feat], gps2.search_info[feat]
+        assert a["best_model"] == b["best_model"] and set(a["models"]) == set(b["models"])
+        for n in a["models"]:
+            assert a["models"][n]["fit"]["loss"] == b["models"][n]["fit"]["loss"], n
 
 
 # ---------------------------------------------------------------------------------------------

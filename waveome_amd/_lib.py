@@ -42,6 +42,11 @@ class KernelSpec(C.Structure):
                 ("mean_param", C.c_int32)]
 
 
+class ProblemCaps(C.Structure):
+    _fields_ = [("max_specs", C.c_int32), ("max_params", C.c_int32), ("max_feat", C.c_int32),
+                ("max_factors", C.c_int32), ("max_red", C.c_int32)]
+
+
 class LbfgsOpts(C.Structure):
     _fields_ = [("m", C.c_int32), ("maxiter", C.c_int32), ("maxfun", C.c_int32),
                 ("maxls", C.c_int32), ("ftol", C.c_double), ("gtol", C.c_double)]
@@ -77,6 +82,16 @@ SIGNATURES = {
     "wv_problem_create_multi": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32,
                                             C.POINTER(C.POINTER(KernelSpec)), C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32, C.POINTER(_vp)]),
+    "wv_problem_create_ex": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32,
+                                         C.POINTER(C.POINTER(KernelSpec)), C.c_int32, C.POINTER(ProblemCaps),
+                                         C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "wv_problem_add_spec": (C.c_int32, [_vp, C.POINTER(KernelSpec), _ip]),
+    "wv_queue_create": (C.c_int32, [_vp, C.POINTER(LbfgsOpts), C.POINTER(_vp)]),
+    "wv_queue_submit": (C.c_int32, [_vp, C.c_int32, _ip, _ip, _dp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
+    "wv_queue_advance": (C.c_int32, [_vp, _ip, _ip]),
+    "wv_queue_fetch": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _dp, _dp, _dp, _ip, _ip, _ip,
+                                   _ip]),
+    "wv_queue_destroy": (None, [_vp]),
     "wv_problem_destroy": (None, [_vp]),
     "wv_problem_workspace_bytes": (C.c_int64, [_vp]),
     "wv_gram": (C.c_int32, [_vp, _dp, _dp]),
@@ -125,7 +140,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.wv_abi_version() != 1:
+    if lib.wv_abi_version() != 2:
         raise WaveomeAmdError("libwaveome_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <memory>
 
@@ -315,6 +316,12 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
                                 int32_t P, const wv_kernel_spec* const* spec_list, int32_t n_specs,
                                 int32_t max_batch, int32_t x_is_device, int32_t y_is_device,
                                 wv_problem** out) {
+  return wv_problem_create_ex(ctx, X, N, D, Y, P, spec_list, n_specs, nullptr, max_batch, x_is_device, y_is_device, out);
+}
+
+int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
+                             const wv_kernel_spec* const* spec_list, int32_t n_specs, const wv_problem_caps* caps,
+                             int32_t max_batch, int32_t x_is_device, int32_t y_is_device, wv_problem** out) {
   if (!ctx || !X || !Y || !spec_list || n_specs < 1 || !out || N < 1 || D < 1 || P < 1 || max_batch < 1) {
     set_error("wv_problem_create: bad argument");
     return WV_E_BADARG;
@@ -354,6 +361,20 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
     p.max_red = std::max(p.max_red, (int)hspecs[si].n_red);
     for (int fi = 0; fi < hspecs[si].n_factors; ++fi) p.any_multidim |= hspecs[si].factors[fi].ndims > 1;
   }
+  p.spec_cap = n_specs;
+  if (caps) {  // room for structures added later (wv_problem_add_spec)
+    if (caps->max_feat > MAX_FEAT || caps->max_factors > 128 || caps->max_specs > (1 << 20)) {
+      set_error("wv_problem_create_ex: capacity beyond the device limits (64 features, 128 factors)");
+      return WV_E_UNSUPPORTED;
+    }
+    p.spec_cap = std::max(p.spec_cap, (int)caps->max_specs);
+    p.np_stride = std::max(p.np_stride, (int)caps->max_params);
+    p.max_feat = std::max(p.max_feat, (int)caps->max_feat);
+    p.max_fact = std::max(p.max_fact, (int)caps->max_factors);
+    p.max_red = std::max(p.max_red, (int)caps->max_red);
+    p.any_multidim = true;  // (later structures may act on several columns: the general trace kernel)
+  }
+  p.specs.reserve(p.spec_cap);
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
   p.spec = p.specs[0];
   p.hspec = hspecs[0];
@@ -376,7 +397,7 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
     return true;
   };
   bool ok = alloc((void**)&p.dX, sizeof(double) * Np * D) && alloc((void**)&p.dY, sizeof(double) * Np * P) &&
-            alloc((void**)&p.dspec, sizeof(DevSpec) * n_specs) &&
+            alloc((void**)&p.dspec, sizeof(DevSpec) * p.spec_cap) &&
             alloc((void**)&p.dslotspec, sizeof(int32_t) * max_batch) &&
             (p.f32 ? alloc((void**)&p.Kbuf32, sizeof(float) * mat * max_batch) &&
                          alloc((void**)&p.Mbuf32, sizeof(float) * mat * max_batch) &&
@@ -591,9 +612,185 @@ int32_t wv_fit(wv_problem* h, const int32_t* col_idx, int32_t n_tasks, const wv_
                           n_eval_out, status_out);
 }
 
-// One work queue over (column, structure) tasks: wv_fit / wv_fit_penalized (one structure) and
-// wv_fit_multi (a structure index per task) share it.  u_stride = doubles between consecutive tasks'
-// start points in theta_u_inout.
+// ---------------------------------------------------------------------------------------------------------------
+// The work queue over (column, structure) tasks.  wv_fit / wv_fit_penalized / wv_fit_multi submit a fixed list and run
+// it dry; wv_queue_* expose it so that a caller can add tasks while others are still being fitted (the kernel search:
+// an output column whose candidates are all scored moves on to its next level without waiting for the other columns).
+// A slot's arithmetic does not depend on what else is in the batch, so both uses give bit-identical fits.
+// ---------------------------------------------------------------------------------------------------------------
+namespace wv {
+
+struct QTask {
+  int32_t col = 0, spec = 0;
+  double prior_scale = -1.0;  // < 0: the spec's own prior scales
+  int64_t tag = 0;
+  std::vector<double> u0;     // n_trainable of the task's structure
+};
+struct QResult {
+  int64_t tag = 0;
+  std::vector<double> u;
+  double loss = 0, lml = 0;
+  int32_t nit = 0, nfev = 0, status = 0;
+};
+
+class FitQueue {
+ public:
+  FitQueue(Problem& p, const wv_lbfgs_opts& o) : p_(p), opts_(o), slots_(p.groups.size()), inflight_(p.groups.size(), 0) {}
+  void submit(QTask&& t) { queue_.push_back(std::move(t)); }
+  size_t in_system() const {
+    size_t n = queue_.size() + held_.size();
+    for (auto& sl : slots_)
+      for (auto& s : sl) n += s.live;
+    return n;
+  }
+  std::deque<QResult> done;
+  // One scheduling step: groups without a launch in flight are (re)filled and launched; then the next group in turn
+  // is waited for, its results are fed to the optimisers, finished fits move to `done`, the group is refilled and
+  // relaunched.  Returns WV_OK (also when there was nothing to do).
+  int advance();
+  void trace(int n_tasks, double wall) const {
+    fprintf(stderr, "[wv_fit] %d tasks, %ld group-rounds, %ld evals (%.1f per round), wall %.3f s: wait %.3f host %.3f launch %.3f\n",
+            n_tasks, n_rounds_, n_evals_, (double)n_evals_ / std::max(1L, n_rounds_), wall, t_wait_, t_host_, t_launch_);
+  }
+
+ private:
+  struct Slot {
+    int live = 0;
+    QTask task;
+    std::unique_ptr<Lbfgs> opt;
+  };
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  int refill_and_launch(int gi);
+  Problem& p_;
+  wv_lbfgs_opts opts_;
+  std::deque<QTask> queue_;
+  std::vector<std::vector<Slot>> slots_;
+  std::vector<int> inflight_;  // number of slots evaluated by the group's pending launch
+  std::vector<Slot> held_;     // drain phase: tasks parked until they can join another group's batch
+  int gi_ = 0;
+  double t_wait_ = 0, t_host_ = 0, t_launch_ = 0;
+  long n_rounds_ = 0, n_evals_ = 0;
+};
+
+int FitQueue::refill_and_launch(int gi) {
+  Group& g = p_.groups[gi];
+  auto& sl = slots_[gi];
+  const int np = p_.np_stride;
+  // drop finished slots, pull new tasks, keep active tasks packed at the front
+  std::vector<Slot> act;
+  for (auto& s : sl)
+    if (s.live) act.push_back(std::move(s));
+  while ((int)act.size() < g.nslots && !queue_.empty()) {
+    Slot s;
+    s.live = 1;
+    s.task = std::move(queue_.front());
+    queue_.pop_front();
+    s.opt.reset(new Lbfgs(p_.specs[s.task.spec].n_trainable(), opts_, s.task.u0.data()));
+    act.push_back(std::move(s));
+  }
+  sl = std::move(act);
+  inflight_[gi] = (int)sl.size();
+  if (sl.empty()) return WV_OK;
+  for (size_t i = 0; i < sl.size(); ++i) {
+    const Spec& sp = p_.specs[sl[i].task.spec];
+    if (sp.n_params() < np) std::fill(g.h_theta + i * np + sp.n_params(), g.h_theta + (i + 1) * np, 0.0);
+    sp.constrain(sl[i].opt->x(), g.h_theta + i * np);
+    g.h_col[i] = sl[i].task.col;
+    g.h_spec[i] = sl[i].task.spec;
+  }
+  return enqueue_eval(p_, g, (int)sl.size(), true);
+}
+
+int FitQueue::advance() {
+  const int ng = (int)p_.groups.size();
+  const int np = p_.np_stride;
+  // idle groups pick up queued work
+  for (int g = 0; g < ng; ++g)
+    if (inflight_[g] == 0 && !queue_.empty()) {
+      double t2 = now();
+      int rc = refill_and_launch(g);
+      if (rc != WV_OK) return rc;
+      t_launch_ += now() - t2;
+    }
+  int busy = 0;
+  for (int g = 0; g < ng; ++g) busy += inflight_[g] > 0;
+  if (busy == 0) return WV_OK;
+  while (inflight_[gi_] == 0) gi_ = (gi_ + 1) % ng;
+  const int gi = gi_;
+  Group& g = p_.groups[gi];
+  double t0 = now();
+  int rc = wait_group(p_, g);
+  if (rc != WV_OK) return rc;
+  double t1 = now();
+  t_wait_ += t1 - t0;
+  auto& sl = slots_[gi];
+  ++n_rounds_;
+  n_evals_ += (long)sl.size();
+  std::vector<double> gu, theta(np);
+  for (size_t i = 0; i < sl.size(); ++i) {
+    Slot& s = sl[i];
+    double loss, lml;
+    // h_theta still holds the constrained table this evaluation used
+    const double ps = s.task.prior_scale;
+    const Spec& sp = p_.specs[s.task.spec];
+    gu.resize(sp.n_trainable());
+    loss_from_record(sp, s.opt->x(), g.h_theta + i * np, g.h_out + i * p_.out_stride, g.h_status[i], &loss, gu.data(),
+                     &lml, ps);
+    int task = s.opt->feed(loss, gu.data());
+    if (task != WV_LB_FG) {
+      // a fit that never saw a finite evaluation (NaN in the column, K_y not positive definite at the
+      // start point) reports loss = +inf, lml = -inf and WV_LB_ABNORMAL - never a finite score
+      QResult r;
+      r.tag = s.task.tag;
+      r.u.assign(s.opt->x(), s.opt->x() + sp.n_trainable());
+      const double f_end = s.opt->f();
+      const bool f_ok = std::isfinite(f_end);
+      r.loss = f_ok ? f_end : std::numeric_limits<double>::infinity();
+      r.nit = s.opt->n_iter();
+      r.nfev = s.opt->n_eval();
+      r.status = f_ok ? task : WV_LB_ABNORMAL;
+      // LML at the returned point = -(loss) - log prior
+      sp.constrain(s.opt->x(), theta.data());
+      r.lml = f_ok ? -f_end - sp.log_prior(theta.data(), nullptr, ps) : -std::numeric_limits<double>::infinity();
+      done.push_back(std::move(r));
+      s.live = 0;
+    }
+  }
+  // Drain phase (queue empty): once everything still running fits in one group, fold the groups
+  // together - half-empty batches cost almost as much as full ones (latency-bound small kernels).
+  if (ng > 1 && queue_.empty()) {
+    int mine = 0, others_inflight = 0, busy_groups = 0;
+    for (auto& s : sl) mine += s.live;
+    for (int o = 0; o < ng; ++o)
+      if (o != gi && inflight_[o] > 0) {
+        others_inflight += inflight_[o];
+        ++busy_groups;
+      }
+    if (busy_groups > 0 && mine + (int)held_.size() + others_inflight <= g.nslots) {
+      for (auto& s : sl)
+        if (s.live) held_.push_back(std::move(s));
+      sl.clear();
+      inflight_[gi] = 0;
+      gi_ = (gi + 1) % ng;
+      return WV_OK;  // these tasks join the next group that finishes
+    }
+    if (!held_.empty() && mine + (int)held_.size() <= g.nslots) {
+      for (auto& s : held_) sl.push_back(std::move(s));
+      held_.clear();
+    }
+  }
+  double t2 = now();
+  t_host_ += t2 - t1;
+  rc = refill_and_launch(gi);
+  if (rc != WV_OK) return rc;
+  t_launch_ += now() - t2;
+  gi_ = (gi + 1) % ng;
+  return WV_OK;
+}
+
+}  // namespace wv
+
+// u_stride = doubles between consecutive tasks' start points in theta_u_inout.
 static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* spec_idx, int32_t n_tasks,
                         const wv_lbfgs_opts* opts, const double* prior_scale, int32_t u_stride,
                         double* theta_u_inout, double* loss_out, double* lml_out, int32_t* n_iter_out,
@@ -602,8 +799,6 @@ static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* sp
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, n_tasks);
   if (rc != WV_OK) return rc;
-  const int np = p.np_stride;
-  int nt_max = 0;
   for (int t = 0; t < n_tasks; ++t) {
     const int si = spec_idx ? spec_idx[t] : 0;
     if (si < 0 || si >= (int)p.specs.size()) {
@@ -619,135 +814,35 @@ static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* sp
       set_error("wv_fit: u_stride smaller than a structure's number of trainable parameters");
       return WV_E_BADARG;
     }
-    nt_max = std::max(nt_max, nt);
   }
-  auto spec_of = [&](int task) -> const Spec& { return p.specs[spec_idx ? spec_idx[task] : 0]; };
-  struct Slot {
-    int task = -1;
-    std::unique_ptr<Lbfgs> opt;
-    double last_lml = 0;
-  };
-  const int ng = (int)p.groups.size();
-  std::vector<std::vector<Slot>> slots(ng);
-  std::vector<int> inflight(ng, 0);  // number of slots evaluated by the pending launch
-  int next_task = 0, finished = 0;
-  std::vector<double> gu(nt_max), theta(np);
-
-  auto refill_and_launch = [&](int gi) -> int {
-    Group& g = p.groups[gi];
-    auto& sl = slots[gi];
-    // drop finished slots, pull new tasks, keep active tasks packed at the front
-    std::vector<Slot> act;
-    for (auto& s : sl)
-      if (s.task >= 0) act.push_back(std::move(s));
-    while ((int)act.size() < g.nslots && next_task < n_tasks) {
-      Slot s;
-      s.task = next_task++;
-      s.opt.reset(new Lbfgs(spec_of(s.task).n_trainable(), *opts, theta_u_inout + (size_t)s.task * u_stride));
-      act.push_back(std::move(s));
-    }
-    sl = std::move(act);
-    inflight[gi] = (int)sl.size();
-    if (sl.empty()) return WV_OK;
-    for (size_t i = 0; i < sl.size(); ++i) {
-      const Spec& sp = spec_of(sl[i].task);
-      if (sp.n_params() < np) std::fill(g.h_theta + i * np + sp.n_params(), g.h_theta + (i + 1) * np, 0.0);
-      sp.constrain(sl[i].opt->x(), g.h_theta + i * np);
-      g.h_col[i] = col_idx[sl[i].task];
-      g.h_spec[i] = spec_idx ? spec_idx[sl[i].task] : 0;
-    }
-    return enqueue_eval(p, g, (int)sl.size(), true);
-  };
-
-  for (int gi = 0; gi < ng; ++gi) {
-    rc = refill_and_launch(gi);
-    if (rc != WV_OK) return rc;
+  FitQueue q(p, *opts);
+  for (int t = 0; t < n_tasks; ++t) {
+    QTask task;
+    task.col = col_idx[t];
+    task.spec = spec_idx ? spec_idx[t] : 0;
+    task.prior_scale = prior_scale ? prior_scale[t] : -1.0;
+    task.tag = t;
+    const double* u0 = theta_u_inout + (size_t)t * u_stride;
+    task.u0.assign(u0, u0 + p.specs[task.spec].n_trainable());
+    q.submit(std::move(task));
   }
-  int gi = 0;
   const bool trace = std::getenv("WV_FIT_TRACE") != nullptr;
-  double t_wait = 0, t_host = 0, t_launch = 0;
-  long n_rounds = 0, n_evals = 0;
-  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_begin = now();
-  std::vector<Slot> held;  // drain phase: tasks parked until they can join another group's batch
-  while (finished < n_tasks) {
-    if (inflight[gi] == 0) {
-      gi = (gi + 1) % ng;
-      continue;
-    }
-    Group& g = p.groups[gi];
-    double t0 = now();
-    rc = wait_group(p, g);
+  const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  while (q.in_system() > 0) {
+    rc = q.advance();
     if (rc != WV_OK) return rc;
-    double t1 = now();
-    t_wait += t1 - t0;
-    auto& sl = slots[gi];
-    ++n_rounds;
-    n_evals += (long)sl.size();
-    for (size_t i = 0; i < sl.size(); ++i) {
-      Slot& s = sl[i];
-      double loss, lml;
-      // h_theta still holds the constrained table this evaluation used
-      const double ps = prior_scale ? prior_scale[s.task] : -1.0;
-      const Spec& sp = spec_of(s.task);
-      loss_from_record(sp, s.opt->x(), g.h_theta + i * np, g.h_out + i * p.out_stride, g.h_status[i], &loss,
-                       gu.data(), &lml, ps);
-      int task = s.opt->feed(loss, gu.data());
-      if (std::isfinite(loss)) s.last_lml = lml;
-      if (task != WV_LB_FG) {
-        const int t = s.task;
-        std::memcpy(theta_u_inout + (size_t)t * u_stride, s.opt->x(), sizeof(double) * sp.n_trainable());
-        // a fit that never saw a finite evaluation (NaN in the column, K_y not positive definite at the
-        // start point) reports loss = +inf, lml = -inf and WV_LB_ABNORMAL - never a finite score
-        const double f_end = s.opt->f();
-        const bool f_ok = std::isfinite(f_end);
-        if (loss_out) loss_out[t] = f_ok ? f_end : std::numeric_limits<double>::infinity();
-        if (n_iter_out) n_iter_out[t] = s.opt->n_iter();
-        if (n_eval_out) n_eval_out[t] = s.opt->n_eval();
-        if (status_out) status_out[t] = f_ok ? task : WV_LB_ABNORMAL;
-        if (lml_out) {
-          // LML at the returned point = -(loss) - log prior
-          sp.constrain(s.opt->x(), theta.data());
-          lml_out[t] = f_ok ? -f_end - sp.log_prior(theta.data(), nullptr, ps)
-                            : -std::numeric_limits<double>::infinity();
-        }
-        s.task = -1;
-        ++finished;
-      }
-    }
-    // Drain phase (queue empty): once everything still running fits in one group, fold the groups
-    // together - half-empty batches cost almost as much as full ones (latency-bound small kernels).
-    if (ng > 1 && next_task >= n_tasks) {
-      int mine = 0, others_inflight = 0, busy_groups = 0;
-      for (auto& s : sl) mine += s.task >= 0;
-      for (int o = 0; o < ng; ++o)
-        if (o != gi && inflight[o] > 0) {
-          others_inflight += inflight[o];
-          ++busy_groups;
-        }
-      if (busy_groups > 0 && mine + (int)held.size() + others_inflight <= g.nslots) {
-        for (auto& s : sl)
-          if (s.task >= 0) held.push_back(std::move(s));
-        sl.clear();
-        inflight[gi] = 0;
-        gi = (gi + 1) % ng;
-        continue;  // these tasks join the next group that finishes
-      }
-      if (!held.empty() && mine + (int)held.size() <= g.nslots) {
-        for (auto& s : held) sl.push_back(std::move(s));
-        held.clear();
-      }
-    }
-    double t2 = now();
-    t_host += t2 - t1;
-    rc = refill_and_launch(gi);
-    if (rc != WV_OK) return rc;
-    t_launch += now() - t2;
-    gi = (gi + 1) % ng;
+  }
+  for (const QResult& r : q.done) {
+    const int t = (int)r.tag;
+    std::memcpy(theta_u_inout + (size_t)t * u_stride, r.u.data(), sizeof(double) * r.u.size());
+    if (loss_out) loss_out[t] = r.loss;
+    if (lml_out) lml_out[t] = r.lml;
+    if (n_iter_out) n_iter_out[t] = r.nit;
+    if (n_eval_out) n_eval_out[t] = r.nfev;
+    if (status_out) status_out[t] = r.status;
   }
   if (trace)
-    fprintf(stderr, "[wv_fit] %d tasks, %ld group-rounds, %ld evals (%.1f per round), wall %.3f s: wait %.3f host %.3f launch %.3f\n",
-            n_tasks, n_rounds, n_evals, (double)n_evals / std::max(1L, n_rounds), now() - t_begin, t_wait, t_host, t_launch);
+    q.trace(n_tasks, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin);
   return WV_OK;
 }
 
@@ -1029,6 +1124,148 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_BADARG;
   }
   return WV_OK;
+}
+
+int32_t wv_problem_add_spec(wv_problem* h, const wv_kernel_spec* spec, int32_t* index_out) {
+  if (!h || !spec || !index_out) {
+    set_error("wv_problem_add_spec: null argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  if ((int)p.specs.size() >= p.spec_cap) {
+    set_error("wv_problem_add_spec: the problem's structure table is full (wv_problem_create_ex caps.max_specs)");
+    return WV_E_UNSUPPORTED;
+  }
+  Spec sp;
+  std::string e = Spec::parse(spec, sp);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (sp.n_dims != p.D) {
+    set_error("spec.n_dims != D");
+    return WV_E_SPEC;
+  }
+  DevSpec d;
+  e = build_devspec(sp, d);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_UNSUPPORTED;
+  }
+  if (sp.n_params() > p.np_stride || d.n_feat > p.max_feat || d.n_factors > p.max_fact || d.n_red > p.max_red) {
+    set_error("wv_problem_add_spec: the structure exceeds a capacity the problem was created with");
+    return WV_E_UNSUPPORTED;
+  }
+  d.n_params = p.np_stride;
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  // the new table entry is referenced by no slot yet, so kernels in flight do not read it
+  WV_HIP_TRY(hipMemcpy(p.dspec + p.specs.size(), &d, sizeof(DevSpec), hipMemcpyHostToDevice));
+  *index_out = (int32_t)p.specs.size();
+  p.specs.push_back(std::move(sp));
+  return WV_OK;
+}
+
+struct wv_queue {
+  wv_problem* prob;
+  std::unique_ptr<FitQueue> q;
+};
+
+int32_t wv_queue_create(wv_problem* h, const wv_lbfgs_opts* opts, wv_queue** out) {
+  if (!h || !opts || !out) {
+    set_error("wv_queue_create: null argument");
+    return WV_E_BADARG;
+  }
+  auto* w = new wv_queue();
+  w->prob = h;
+  w->q.reset(new FitQueue(h->p, *opts));
+  *out = w;
+  return WV_OK;
+}
+
+int32_t wv_queue_submit(wv_queue* w, int32_t n, const int32_t* col_idx, const int32_t* spec_idx,
+                        const double* prior_scale, int32_t u_stride, const double* theta_u0, const int64_t* tags) {
+  if (!w || n < 0 || (n > 0 && (!col_idx || !spec_idx || !theta_u0 || !tags)) || u_stride < 1) {
+    set_error("wv_queue_submit: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = w->prob->p;
+  int rc = check_cols(p, col_idx, n);
+  if (rc != WV_OK) return rc;
+  for (int t = 0; t < n; ++t) {
+    if (spec_idx[t] < 0 || spec_idx[t] >= (int)p.specs.size()) {
+      set_error("wv_queue_submit: structure index out of range");
+      return WV_E_BADARG;
+    }
+    const int nt = p.specs[spec_idx[t]].n_trainable();
+    if (nt < 1 || nt > u_stride) {
+      set_error("wv_queue_submit: structure without trainable parameters, or u_stride too small");
+      return nt < 1 ? WV_E_SPEC : WV_E_BADARG;
+    }
+  }
+  for (int t = 0; t < n; ++t) {
+    QTask task;
+    task.col = col_idx[t];
+    task.spec = spec_idx[t];
+    task.prior_scale = prior_scale ? prior_scale[t] : -1.0;
+    task.tag = tags[t];
+    const double* u0 = theta_u0 + (size_t)t * u_stride;
+    task.u0.assign(u0, u0 + p.specs[task.spec].n_trainable());
+    w->q->submit(std::move(task));
+  }
+  return WV_OK;
+}
+
+int32_t wv_queue_advance(wv_queue* w, int32_t* n_done_out, int32_t* n_in_system_out) {
+  if (!w) {
+    set_error("wv_queue_advance: null queue");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(w->prob->p.ctx->device));
+  int rc = w->q->advance();
+  if (rc != WV_OK) return rc;
+  if (n_done_out) *n_done_out = (int32_t)w->q->done.size();
+  if (n_in_system_out) *n_in_system_out = (int32_t)w->q->in_system();
+  return WV_OK;
+}
+
+int32_t wv_queue_fetch(wv_queue* w, int32_t cap, int32_t u_stride, int64_t* tags_out, double* theta_u_out,
+                       double* loss_out, double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out,
+                       int32_t* status_out, int32_t* n_out) {
+  if (!w || cap < 0 || !n_out || (cap > 0 && (!tags_out || !theta_u_out)) || u_stride < 1) {
+    set_error("wv_queue_fetch: bad argument");
+    return WV_E_BADARG;
+  }
+  int n = 0;
+  while (n < cap && !w->q->done.empty()) {
+    const QResult& r = w->q->done.front();
+    if ((int)r.u.size() > u_stride) {
+      set_error("wv_queue_fetch: u_stride smaller than a fit's number of trainable parameters");
+      return WV_E_BADARG;
+    }
+    tags_out[n] = r.tag;
+    std::fill(theta_u_out + (size_t)n * u_stride, theta_u_out + (size_t)(n + 1) * u_stride, 0.0);
+    std::memcpy(theta_u_out + (size_t)n * u_stride, r.u.data(), sizeof(double) * r.u.size());
+    if (loss_out) loss_out[n] = r.loss;
+    if (lml_out) lml_out[n] = r.lml;
+    if (n_iter_out) n_iter_out[n] = r.nit;
+    if (n_eval_out) n_eval_out[n] = r.nfev;
+    if (status_out) status_out[n] = r.status;
+    w->q->done.pop_front();
+    ++n;
+  }
+  *n_out = n;
+  return WV_OK;
+}
+
+void wv_queue_destroy(wv_queue* w) {
+  if (!w) return;
+  // let launches in flight finish before the staging buffers are reused
+  if (w->prob && w->prob->p.ctx) {
+    (void)hipSetDevice(w->prob->p.ctx->device);
+    for (auto& g : w->prob->p.groups)
+      if (g.stream) (void)hipStreamSynchronize(g.stream);
+  }
+  delete w;
 }
 
 int32_t wv_stage_times(wv_problem* h, int32_t cap, const char** names_out, double* ms_out,

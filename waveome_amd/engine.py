@@ -90,7 +90,7 @@ class Context:
 class Problem:
     def __init__(self, ctx: Context, X, Y, spec: ModelSpec, max_batch: int = 8,
                  x_device_ptr: Optional[int] = None, y_device_ptr: Optional[int] = None,
-                 shape: Optional[Sequence[int]] = None):
+                 shape: Optional[Sequence[int]] = None, capacity: Optional[dict] = None):
         """X: (N, D) array, Y: (N, P) array (one column per output).  Alternatively pass raw device
         pointers (x_device_ptr -> N x D row-major, y_device_ptr -> P x N row-major) with
         shape=(N, D, P), e.g. buffers filled by an RCCL broadcast."""
@@ -118,7 +118,15 @@ class Problem:
             self._X = X
             xp, yp, xd, yd = C.c_void_p(X.ctypes.data), C.c_void_p(self._Yt.ctypes.data), 0, 0
         self.N, self.D, self.P, self.max_batch = N, D, P, int(max_batch)
-        if len(self.specs) == 1:
+        if capacity is not None:
+            # room for structures added later (add_spec): max_specs / max_params / max_feat / max_factors / max_red
+            caps = _lib.ProblemCaps(**{k: int(capacity.get(k, 0)) for k in
+                                       ("max_specs", "max_params", "max_feat", "max_factors", "max_red")})
+            arr = (C.POINTER(_lib.KernelSpec) * len(self.specs))(*[C.pointer(cs) for cs in self._cspecs])
+            _lib.check(self.lib.wv_problem_create_ex(ctx.handle, xp, N, D, yp, P, arr, len(self.specs), C.byref(caps),
+                                                     int(max_batch), xd, yd, C.byref(self.handle)),
+                       "wv_problem_create_ex")
+        elif len(self.specs) == 1:
             _lib.check(self.lib.wv_problem_create(ctx.handle, xp, N, D, yp, P, C.byref(self._cspec),
                                                   int(max_batch), xd, yd, C.byref(self.handle)),
                        "wv_problem_create")
@@ -140,6 +148,15 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    def add_spec(self, spec: ModelSpec) -> int:
+        """Add a kernel structure to a problem created with `capacity`; returns its spec index."""
+        cs = spec.to_ctypes()
+        idx = C.c_int32()
+        _lib.check(self.lib.wv_problem_add_spec(self.handle, C.byref(cs), C.byref(idx)), "wv_problem_add_spec")
+        self.specs.append(spec)
+        self._cspecs.append(cs)
+        return int(idx.value)
 
     @property
     def workspace_bytes(self):
@@ -277,3 +294,66 @@ class Problem:
         _lib.check(self.lib.wv_dbg_stage(self.handle, int(col), _lib.as_dp(theta), int(what), _lib.as_dp(out)),
                    "wv_dbg_stage")
         return out
+
+
+class FitQueue:
+    """The fit work queue of a (multi-structure) Problem, fed incrementally (wv_queue_*): `submit` tasks at any time,
+    `advance` runs one scheduling step, `fetch` returns finished fits.  Fits equal Problem.fit_multi's bit for bit."""
+
+    def __init__(self, prob: Problem, opts=None, width: Optional[int] = None):
+        self.prob, self.lib = prob, prob.lib
+        self.opts = opts or lbfgs_opts()
+        self.width = int(width or max(sp.n_trainable for sp in prob.specs))
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.wv_queue_create(prob.handle, C.byref(self.opts), C.byref(self.handle)), "wv_queue_create")
+        self.done = self.in_system = 0
+
+    def submit(self, cols, spec_idx, U0, tags, prior_scale=None):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        sidx = np.ascontiguousarray(spec_idx, dtype=np.int32)
+        tags = np.ascontiguousarray(tags, dtype=np.int64)
+        U = np.ascontiguousarray(np.atleast_2d(U0), dtype=np.float64)
+        T = len(cols)
+        if U.shape[0] != T or len(sidx) != T or len(tags) != T:
+            raise ValueError("cols, spec_idx, U0 and tags disagree on the number of tasks")
+        ps = None
+        if prior_scale is not None:
+            ps = np.ascontiguousarray(np.broadcast_to(prior_scale, (T,)), dtype=np.float64)
+        _lib.check(self.lib.wv_queue_submit(self.handle, T, _lib.as_ip(cols), _lib.as_ip(sidx),
+                                            _lib.as_dp(ps) if ps is not None else None, U.shape[1], _lib.as_dp(U),
+                                            tags.ctypes.data_as(C.POINTER(C.c_int64))), "wv_queue_submit")
+        self.in_system += T
+
+    def advance(self):
+        """One scheduling step; returns (finished fits waiting, tasks queued or in flight)."""
+        d, n = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.wv_queue_advance(self.handle, C.byref(d), C.byref(n)), "wv_queue_advance")
+        self.done, self.in_system = int(d.value), int(n.value)
+        return self.done, self.in_system
+
+    def fetch(self, cap: int = 4096):
+        """dict of arrays (tag, u, loss, lml, nit, nfev, status) for up to `cap` finished fits, oldest first."""
+        w = self.width
+        tags = np.empty(cap, dtype=np.int64)
+        U = np.empty((cap, w))
+        loss, lml = np.empty(cap), np.empty(cap)
+        nit, nfev, st = (np.empty(cap, dtype=np.int32) for _ in range(3))
+        n = C.c_int32()
+        _lib.check(self.lib.wv_queue_fetch(self.handle, cap, w, tags.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           _lib.as_dp(U), _lib.as_dp(loss), _lib.as_dp(lml), _lib.as_ip(nit),
+                                           _lib.as_ip(nfev), _lib.as_ip(st), C.byref(n)), "wv_queue_fetch")
+        k = int(n.value)
+        self.done = max(0, self.done - k)
+        return {"tag": tags[:k], "u": U[:k], "loss": loss[:k], "lml": lml[:k], "nit": nit[:k], "nfev": nfev[:k],
+                "status": st[:k]}
+
+    def close(self):
+        if self.handle:
+            self.lib.wv_queue_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -438,6 +438,178 @@ class GpuScorer:
         return out
 
 
+class _SearchSession:
+    """One growable multi-structure problem and its work queue for a whole search (wv_problem_create_ex /
+    wv_problem_add_spec / wv_queue_*): candidates are submitted as they are asked for and scored fits come back as
+    they finish, so an output column never waits for another column's depth level."""
+
+    # room for the structures of a search: every structure must fit these (one that does not is scored through the
+    # blocking path).  Kept moderate on purpose - the Gram / trace kernels size their LDS by max_feat / max_red.
+    CAPS = {"max_specs": 4096, "max_params": 40, "max_feat": 24, "max_factors": 24, "max_red": 48}
+
+    def __init__(self, scorer: "GpuScorer"):
+        from .engine import FitQueue
+        from .model_search import _default_batch
+
+        self.sc = scorer
+        self.N = scorer.X.shape[0]
+        self.sig_index: Dict[str, int] = {}
+        self.waiters: Dict[tuple, list] = {}   # (col, sig) -> [callback(fit)] while the fits are in flight
+        self.tasks: Dict[int, tuple] = {}      # tag -> (col, sig, restart index)
+        self.partial: Dict[tuple, list] = {}   # (col, sig) -> results of its restarts so far
+        self.next_tag = 0
+        self.prob = None
+        self.queue = None
+        self._FitQueue = FitQueue
+        self.mb = scorer.max_batch or _default_batch(self.N)
+
+    def _open(self, first_spec: ModelSpec):
+        self.prob = self.sc.shared.problem(self.sc.ctx, [first_spec], max(1, self.mb), capacity=self.CAPS)
+        self.queue = self._FitQueue(self.prob, self.sc.opts, width=self.CAPS["max_params"])
+
+    def request(self, col: int, kernel, callback):
+        """Score (col, kernel); `callback(fit or None)` fires at once on a cache hit, else when the fit is done."""
+        from . import _lib
+
+        sc = self.sc
+        spec = sc._spec(kernel)
+        sig = structure_signature(spec)
+        key = (col, sig)
+        if key in sc.cache:
+            callback(sc.cache[key])
+            return
+        if key in self.waiters:
+            self.waiters[key].append(callback)
+            return
+        if sig not in self.sig_index:
+            try:
+                if self.prob is None:
+                    self._open(spec)
+                    self.sig_index[sig] = 0
+                else:
+                    self.sig_index[sig] = self.prob.add_spec(spec)
+                sc.n_structures += 1
+            except _lib.WaveomeAmdError:
+                # beyond the session's capacities: the blocking path, in its own problem
+                callback(sc([(col, kernel)])[0])
+                return
+        sidx = self.sig_index[sig]
+        R = sc.num_restart
+        self.waiters[key] = [callback]
+        self.partial[key] = []
+        U0 = np.zeros((R, self.queue.width))
+        nt = spec.n_trainable
+        U0[:, :nt] = spec.unconstrain() if R == 1 else restart_points(nt, R, random_seed=sc.random_seed)
+        tags = np.arange(self.next_tag, self.next_tag + R, dtype=np.int64)
+        for r, tg in enumerate(tags):
+            self.tasks[int(tg)] = (col, sig, spec)
+        self.next_tag += R
+        self.queue.submit(np.full(R, col, dtype=np.int32), np.full(R, sidx, dtype=np.int32), U0, tags)
+        sc.n_fits += 1
+
+    def busy(self) -> bool:
+        return self.queue is not None and (self.queue.in_system > 0 or self.queue.done > 0)
+
+    def pump(self):
+        """One scheduling step of the queue; fires the callbacks of the candidates that finished."""
+        if self.queue is None:
+            return
+        done, _ = self.queue.advance()
+        if not done:
+            return
+        res = self.queue.fetch(max(done, 64))
+        sc = self.sc
+        for j, tg in enumerate(res["tag"]):
+            col, sig, spec = self.tasks.pop(int(tg))
+            key = (col, sig)
+            self.partial[key].append((res["lml"][j], res["loss"][j], res["nit"][j], res["nfev"][j], res["status"][j],
+                                      res["u"][j, :spec.n_trainable].copy()))
+            if len(self.partial[key]) < sc.num_restart:
+                continue
+            runs = self.partial.pop(key)
+            # restarts: the fit with the best maximum_log_likelihood_objective is scored (kernel_test :2283-2288)
+            best = max(runs, key=lambda r: r[0] if np.isfinite(r[0]) else -np.inf)
+            lml, loss, nit, nfev, status, u = best
+            if not np.isfinite(loss):
+                fit = None
+            else:
+                k_count = sum(1 for q in spec.param_objs if q.trainable) + 2
+                fit = {"bic": round(calc_bic(loglik=-loss, n=self.N, k=k_count), 2), "loss": float(loss),
+                       "lml": float(lml), "nit": int(nit), "nfev": int(nfev), "status": int(status), "u": u}
+            sc.cache[key] = fit
+            for cb in self.waiters.pop(key):
+                cb(fit)
+
+    def close(self):
+        if self.queue is not None:
+            self.queue.close()
+        if self.prob is not None:
+            self.prob.close()
+        self.queue = self.prob = None
+
+
+def run_searches_async(columns: Sequence[int], n_features: int, kern_list: Sequence, scorer: "GpuScorer",
+                       cat_vars: Sequence[int] = (), verbose: bool = False, session=None,
+                       **search_kwargs) -> Dict[int, dict]:
+    """The searches of `run_searches` without its lock step: every output column's generator gets the fits it asked
+    for as soon as they are all done and its next candidates join the running work queue at once - as in the
+    reference, where each column is its own Ray task (model_search.py:1200-1222).  Same fits (a fit depends only on
+    (structure, column)), hence the same search trees and best models; single process only.
+    `session`: anything with request(col, kernel, callback) / busy() / pump() / close() (test seam)."""
+    session = session or _SearchSession(scorer)
+    gens, results = {}, {}
+    pending: Dict[int, dict] = {}  # col -> {"names": [...], "fits": {name: fit}, "left": int}
+    ready: List[int] = []
+
+    def ask(c, cands):
+        st = {"names": list(cands), "fits": {}, "left": len(cands)}
+        pending[c] = st
+
+        def make_cb(name):
+            def cb(fit):
+                st["fits"][name] = fit
+                st["left"] -= 1
+                if st["left"] == 0:
+                    ready.append(c)
+            return cb
+
+        for name, kern in cands.items():
+            session.request(c, kern, make_cb(name))
+        if not cands:
+            ready.append(c)
+
+    try:
+        for c in columns:
+            g = full_kernel_search_steps(n_features, kern_list, cat_vars=cat_vars, **search_kwargs)
+            try:
+                req = next(g)
+                gens[c] = g
+                ask(c, req)
+            except StopIteration as e:  # pragma: no cover - a search always scores depth 1
+                results[c] = e.value
+        steps = 0
+        while pending:
+            while ready:
+                c = ready.pop()
+                st = pending.pop(c)
+                try:
+                    ask(c, gens[c].send(st["fits"]))
+                except StopIteration as e:
+                    results[c] = e.value
+            if not pending:
+                break
+            if not session.busy():
+                raise RuntimeError("search stalled: candidates pending but no fit in flight")  # pragma: no cover
+            session.pump()
+            steps += 1
+        if verbose:
+            print(f"asynchronous search: {getattr(scorer, 'n_fits', '?')} candidate fits over "
+                  f"{getattr(scorer, 'n_structures', '?')} structures in {steps} queue steps")
+    finally:
+        session.close()
+    return results
+
+
 def run_searches(columns: Sequence[int], n_features: int, kern_list: Sequence, scorer: Callable,
                  cat_vars: Sequence[int] = (), verbose: bool = False, **search_kwargs) -> Dict[int, dict]:
     """Advance one `full_kernel_search_steps` generator per output column in lock step, pooling the

@@ -379,9 +379,16 @@ class GPSearch:
         if scorer is None:
             scorer = ks.GpuScorer(Xn, Yn, context=context, max_batch=max_batch, num_restart=num_restart,
                                   random_seed=random_seed, shared=shared)
-        out = ks.run_searches(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
-                              max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
-                              early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)
+        # one process, the default scorer: the columns' searches run unsynchronised on one growing work queue
+        # (WV_SEARCH_ASYNC=0: level by level); under torch.distributed the levels are sharded over the ranks
+        import os
+
+        use_async = (scorer.__class__ is ks.GpuScorer and scorer.mode == "multi" and not parallel.dist_active()
+                     and os.environ.get("WV_SEARCH_ASYNC", "1") != "0")
+        drive = ks.run_searches_async if use_async else ks.run_searches
+        out = drive(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
+                    max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
+                    early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)
         self.models, self.search_info = {}, {}
         for p, feat in enumerate(self.out_names):
             res = out[p]

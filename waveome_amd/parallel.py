@@ -94,7 +94,7 @@ class SharedInputs:
     def __init__(self, X, Y, Xt=None, Yt=None):
         self.X, self.Y, self._Xt, self._Yt = X, Y, Xt, Yt
 
-    def problem(self, ctx, spec, max_batch):
+    def problem(self, ctx, spec, max_batch, capacity=None):
         """engine.Problem on these inputs: from the broadcast's device tensors when they live on ctx's GPU
         (device-to-device copy inside wv_problem_create), from the host copies otherwise."""
         from .engine import Problem
@@ -102,8 +102,8 @@ class SharedInputs:
         if self._Xt is not None and self._Xt.is_cuda and self._Xt.device.index == ctx.device:
             N, D = self.X.shape
             return Problem(ctx, None, None, spec, max_batch=max_batch, x_device_ptr=self._Xt.data_ptr(),
-                           y_device_ptr=self._Yt.data_ptr(), shape=(N, D, self.Y.shape[1]))
-        return Problem(ctx, self.X, self.Y, spec, max_batch=max_batch)
+                           y_device_ptr=self._Yt.data_ptr(), shape=(N, D, self.Y.shape[1]), capacity=capacity)
+        return Problem(ctx, self.X, self.Y, spec, max_batch=max_batch, capacity=capacity)
 
 
 def broadcast_inputs(X: np.ndarray, Y: np.ndarray, src: int = 0, device=None) -> SharedInputs:
