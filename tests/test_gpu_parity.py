@@ -84,6 +84,21 @@ def test_mfma_gemm_variants(ctx, a_kc, b_kc, bn):
     np.testing.assert_array_equal(out, ref)  # bit-exact on integers
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (False, False)])
+def test_mfma_gemm_small_tile(ctx, a_kc, b_kc):
+    """The 64 x 64 block tile of the few-fits regime (launch_gemm tile code 32), plain-output layouts; its
+    transposed-output instantiations are what every single-fit test below runs through."""
+    rng = np.random.default_rng(11)
+    nb, M, N, Kd = 3, 192, 320, 80
+    A = rng.integers(-8, 9, size=(nb, M, Kd)).astype(float)
+    B = rng.integers(-8, 9, size=(nb, N, Kd)).astype(float)
+    C0 = rng.integers(-8, 9, size=(nb, M, N)).astype(float)
+    Ain = A if a_kc else np.ascontiguousarray(A.transpose(0, 2, 1))
+    Bin = B if b_kc else np.ascontiguousarray(B.transpose(0, 2, 1))
+    out = ctx.dbg_gemm(Ain, Bin, C0, a_kcontig=a_kc, b_kcontig=b_kc, bn=32, alpha=-1.0, beta=1.0)
+    np.testing.assert_array_equal(out, C0 - np.einsum("bmk,bnk->bmn", A, B))
+
+
 def test_mfma_gemm_random_fp64(ctx):
     rng = np.random.default_rng(2)
     A = rng.normal(size=(2, 256, 512))

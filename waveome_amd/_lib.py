@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwaveome_amd.so")
+# (WAVEOME_AMD_LIB: a diagnostic build of the same sources, e.g. tools/libwv_stamps.so)
+LIB_PATH = os.environ.get("WAVEOME_AMD_LIB") or os.path.join(_HERE, "libwaveome_amd.so")
 
 WV_OK = 0
 # factor types

@@ -11,6 +11,8 @@
 //   cholesky / trtri   the first, right-looking schedule (outer 256, inner 64 panels); still used by the
 //                      stand-alone factor of wv_whitened_means and by wv_dbg_stage(what = 0)
 // Storage type R is double, or float on a float32 context; vectors and reductions are always double.
+#include <type_traits>
+
 #include "wv_device.hpp"
 
 namespace wv {
@@ -195,83 +197,226 @@ void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
 // ---------------------------------------------------------------------------------------
 // potrf128: the whole recursion node of size 128 in ONE kernel - factor + invert the 64 x 64 block at (o, o),
 // S = A21 M11', A22 -= S S', T = S M11, factor + invert the Schur complement, M21 = -M22 T - instead of two
-// leaf launches and four 64^3 GEMM launches.  Same thread layout as potrf_diag_kernel (16 x 16 threads, 4 x 4
-// elements each); the three 64^3 products run on the fp64 VALU out of LDS (2 MFLOP per matrix: noise next to the
-// launches they replace, which are pure latency at this size).  Writes M and M' of the 128 block and the two
-// log-det partials; K's own blocks are dead after this node and are not written back.
+// leaf launches and four 64^3 GEMM launches.  Writes M and M' of the 128 block and the two log-det partials; K's own
+// blocks are dead after this node and are not written back.
+//
+// With one fit in flight the sixteen leaves of an N = 2048 evaluation are a dependent chain, so this kernel is
+// built for the latency of ONE workgroup (round 2; shader-clock stamps of the phases: tools/probe_potrf_stamps.py):
+//   * factor64b: 16 x 16 threads x (4 x 4) registers, FOUR columns per step - the diagonal thread factors its 4 x 4
+//     block in registers, the panel threads solve against it, everyone below updates: two barriers per four
+//     columns instead of one per column; the 4 x 4 inverses are formed afterwards, sixteen threads at once;
+//   * the 64^3 products and the two upper levels of the triangular inversion run on v_mfma_f64_4x4x4_4b out of LDS
+//     (wave_mma; the lane maps are those of wv_gemm.hip) instead of fp64 VALU dot products.
 // ---------------------------------------------------------------------------------------
+#ifdef WV_STAMPS  // diagnostic build only (tools/probe_potrf_stamps.py): cycle stamps of workgroup 0's thread 0
+__device__ unsigned long long wv_stamps[32];
+#define WV_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0) wv_stamps[i] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define WV_STAMP(i)
+#endif
+
+// acc[ia][jc][r] += sum over k in [kbeg, kend) of A(16 ia + 4 blk + e, k) * B(k, 16 jc + 4 ((blk + r0 + r) & 3) + e)
+// for this lane's (k, blk, e) = (lane >> 4, (lane >> 2) & 3, lane & 3); kbeg, kend multiples of 4.
+//   A(row, k) = AT ? A[k * lda + row] : A[row * lda + k]      B(k, col) = BT ? B[col * ldb + k] : B[k * ldb + col]
+// Afterwards element (i, j) = (lane >> 4, lane & 3) of block blk of acc[ia][jc][r] is the product's entry
+// (16 ia + 4 blk + i, 16 jc + 4 ((blk + r0 + r) & 3) + j): see mma_rc.
+template <int NA, int NC, int NR, bool AT, bool BT, typename R>
+__device__ inline void wave_mma(double (&acc)[NA][NC][NR], const R* __restrict__ A, int lda, const R* __restrict__ B,
+                                int ldb, int kbeg, int kend, int r0, int lane) {
+  const int fk = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
+  for (int k0 = kbeg; k0 < kend; k0 += 4) {
+    const int k = k0 + fk;
+    double af[NA];
+#pragma unroll
+    for (int ia = 0; ia < NA; ++ia) {
+      const int row = 16 * ia + 4 * blk + e;
+      af[ia] = (double)(AT ? A[k * lda + row] : A[row * lda + k]);
+    }
+#pragma unroll
+    for (int jc = 0; jc < NC; ++jc)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int col = 16 * jc + 4 * ((blk + r0 + r) & 3) + e;
+        const double bf = (double)(BT ? B[col * ldb + k] : B[k * ldb + col]);
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) acc[ia][jc][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[ia], bf, acc[ia][jc][r], 0, 0, 0);
+      }
+  }
+}
+// row / column (relative to the wave's tile) of this lane's element of acc[ia][jc][r]
+__device__ inline int mma_row(int ia, int lane) { return 16 * ia + 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ inline int mma_col(int jc, int r, int r0, int lane) {
+  return 16 * jc + 4 * ((((lane >> 2) & 3) + r0 + r) & 3) + (lane & 3);
+}
+template <int NA, int NC, int NR>
+__device__ inline void mma_zero(double (&acc)[NA][NC][NR]) {
+#pragma unroll
+  for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+    for (int jc = 0; jc < NC; ++jc)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[ia][jc][r] = 0.0;
+}
+// C(row, col) = sign * acc, C row-major with leading dimension ldc, pre-offset to the wave's tile
+template <int NA, int NC, int NR, typename R>
+__device__ inline void mma_store(const double (&acc)[NA][NC][NR], R* __restrict__ C, int ldc, double sign, int r0, int lane) {
+#pragma unroll
+  for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+    for (int jc = 0; jc < NC; ++jc)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) C[mma_row(ia, lane) * ldc + mma_col(jc, r, r0, lane)] = (R)(sign * acc[ia][jc][r]);
+}
+
+// Blocked register-tiled Cholesky of a 64 x 64 block held as 4 x 4 per thread (16 x 16 threads), four columns per
+// step.  dinfo[jb][0..9]: diagonal block jb's sub-diagonal entries and reciprocal pivots (kept for all sixteen
+// blocks: diag_inverses turns them into the 4 x 4 inverses afterwards); pbuf[64][4]: the solved panel.
+// Returns "this thread saw a non-positive / NaN pivot".
+constexpr int DINFO = 10;
 template <typename R>
-__device__ inline bool factor64(R (&a)[4][4], R (*colbuf)[NB], int ty, int tx) {
+__device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restrict__ pbuf, int ty, int tx) {
   bool anybad = false;
   for (int jb = 0; jb < 16; ++jb) {
+    R* dbuf = dinfo + DINFO * jb;
+    if (ty == jb && tx == jb) {
+      R inv[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = 4 * jb + jj;
-      R* cb = colbuf[j & 1];
-      if (tx == jb && ty >= jb) {
+      for (int c = 0; c < 4; ++c) {
+        R piv = a[c][c];
+        const bool ok = piv > R(0);  // false for NaN as well
+        if (!ok) { piv = 1; anybad = true; }
+        inv[c] = rsq(piv);
+        a[c][c] = piv * inv[c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cb[4 * ty + r] = a[r][jj];
+        for (int r = c + 1; r < 4; ++r) a[r][c] *= inv[c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < 4; ++c2)
+#pragma unroll
+          for (int r = c2; r < 4; ++r) a[r][c2] -= a[r][c] * a[c2][c];
       }
-      __syncthreads();
-      R piv = cb[j];
-      const bool ok = piv > R(0);
-      if (!ok) { piv = 1; anybad = true; }
-      const R inv = rsq(piv);
-      if (ty >= tx && tx >= jb) {
-        R lr[4], lc[4];
+      dbuf[0] = a[1][0]; dbuf[1] = a[2][0]; dbuf[2] = a[3][0]; dbuf[3] = a[2][1]; dbuf[4] = a[3][1]; dbuf[5] = a[3][2];
+      dbuf[6] = inv[0]; dbuf[7] = inv[1]; dbuf[8] = inv[2]; dbuf[9] = inv[3];
+    }
+    __syncthreads();
+    if (tx == jb && ty > jb) {  // panel: rows of this thread times inv(L_jj)'
+      const R l10 = dbuf[0], l20 = dbuf[1], l30 = dbuf[2], l21 = dbuf[3], l31 = dbuf[4], l32 = dbuf[5];
+      const R i0 = dbuf[6], i1 = dbuf[7], i2 = dbuf[8], i3 = dbuf[9];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lr[r] = cb[4 * ty + r] * inv;
+      for (int r = 0; r < 4; ++r) {
+        const R x0 = a[r][0] * i0;
+        const R x1 = (a[r][1] - x0 * l10) * i1;
+        const R x2 = (a[r][2] - x0 * l20 - x1 * l21) * i2;
+        const R x3 = (a[r][3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+        a[r][0] = x0; a[r][1] = x1; a[r][2] = x2; a[r][3] = x3;
+        R* pr = pbuf + (4 * ty + r) * 4;
+        pr[0] = x0; pr[1] = x1; pr[2] = x2; pr[3] = x3;
+      }
+    }
+    __syncthreads();
+    if (tx > jb && ty >= tx) {
+      R lr[4][4], lc[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) lc[c] = cb[4 * tx + c] * inv;
-        if (tx == jb) {
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a[r][jj] = (ty == jb && r == jj) ? piv * inv : lr[r];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (c > jj) a[r][c] -= lr[r] * lc[c];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) a[r][c] -= lr[r] * lc[c];
+        for (int k = 0; k < 4; ++k) {
+          lr[r][k] = pbuf[(4 * ty + r) * 4 + k];
+          lc[r][k] = pbuf[(4 * tx + r) * 4 + k];
         }
-      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[r][c] -= lr[r][k] * lc[c][k];
     }
   }
   return anybad;
 }
 
-// L (lower, LDS) -> X = L^-1 (LDS; must be zero on entry), T scratch.  Ends with a barrier.
+// The sixteen 4 x 4 diagonal blocks of X = L^-1 from factor64b's dinfo (one thread per block; X is zero elsewhere).
+// The caller puts a barrier between factor64b and this, and another before X is read.
 template <typename R>
-__device__ inline void invert64(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
-  if (tid < 64) {
-    const int blk = tid >> 2, c = tid & 3, o = blk * 4;
-    X[(o + c) * DS + o + c] = R(1) / L[(o + c) * DS + o + c];
-    for (int i = c + 1; i < 4; ++i) {
-      R s = 0;
-      for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
-      X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
-    }
+__device__ inline void diag_inverses(const R* __restrict__ dinfo, R* __restrict__ X, int tid) {
+  if ((tid & 15) == 0) {  // (four threads in each wave)
+    const int jb = tid >> 4;
+    const R* d = dinfo + DINFO * jb;
+    const R l10 = d[0], l20 = d[1], l30 = d[2], l21 = d[3], l31 = d[4], l32 = d[5];
+    const R i0 = d[6], i1 = d[7], i2 = d[8], i3 = d[9];
+    const R x10 = -i1 * (l10 * i0);
+    const R x21 = -i2 * (l21 * i1);
+    const R x32 = -i3 * (l32 * i2);
+    const R x20 = -i2 * (l20 * i0 + l21 * x10);
+    const R x31 = -i3 * (l31 * i1 + l32 * x21);
+    const R x30 = -i3 * (l30 * i0 + l31 * x10 + l32 * x20);
+    R* xd = X + (4 * jb) * DS + 4 * jb;
+    xd[0] = i0;
+    xd[DS] = x10; xd[DS + 1] = i1;
+    xd[2 * DS] = x20; xd[2 * DS + 1] = x21; xd[2 * DS + 2] = i2;
+    xd[3 * DS] = x30; xd[3 * DS + 1] = x31; xd[3 * DS + 2] = x32; xd[3 * DS + 3] = i3;
+  }
+}
+
+// Upper levels of the triangular inversion on the MFMA: for every 2H diagonal block X21 = -X22 (L21 X11), H = 16
+// (two blocks, two waves each) or 32 (one block, the four waves as 2 x 2).  T: H x H scratch per block, row-major.
+template <int H, typename R>
+__device__ inline void inv_level_mma(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  if (H == 16) {
+    const int o = 32 * (w >> 1), r0 = 2 * (w & 1);
+    R* Tp = T + 256 * (w >> 1);
+    double acc[1][1][2];
+    mma_zero(acc);
+    wave_mma<1, 1, 2, false, false>(acc, L + (o + 16) * DS + o, DS, X + o * DS + o, DS, 0, 16, r0, lane);
+    mma_store(acc, Tp, 16, 1.0, r0, lane);
+    __syncthreads();
+    mma_zero(acc);
+    wave_mma<1, 1, 2, false, false>(acc, X + (o + 16) * DS + o + 16, DS, Tp, 16, 0, 16, r0, lane);
+    mma_store(acc, X + (o + 16) * DS + o, DS, -1.0, r0, lane);
+  } else {
+    const int ia = w >> 1, jc = w & 1;
+    double acc[1][1][4];
+    mma_zero(acc);  // X11 is lower triangular: rows k < 16 jc of its columns 16 jc.. are zero
+    wave_mma<1, 1, 4, false, false>(acc, L + (32 + 16 * ia) * DS, DS, X + 16 * jc, DS, 16 * jc, 32, 0, lane);
+    mma_store(acc, T + (16 * ia) * 32 + 16 * jc, 32, 1.0, 0, lane);
+    __syncthreads();
+    mma_zero(acc);  // X22 is lower triangular: columns k >= 16 (ia + 1) of its rows 16 ia.. are zero
+    wave_mma<1, 1, 4, false, false>(acc, X + (32 + 16 * ia) * DS + 32, DS, T + 16 * jc, 32, 0, 16 * ia + 16, 0, lane);
+    mma_store(acc, X + (32 + 16 * ia) * DS + 16 * jc, DS, -1.0, 0, lane);
   }
   __syncthreads();
+}
+
+// L (lower, LDS) -> X = L^-1 (LDS).  On entry X holds the inverses of the sixteen 4 x 4 diagonal blocks
+// (diag_inverses) and zeros elsewhere.  Ends with a barrier.
+template <typename R>
+__device__ inline void invert64(const R* __restrict__ L, R* __restrict__ X, R* __restrict__ T, int tid) {
+  WV_STAMP(16);
   inv_level<4>(L, X, T, tid);
+  WV_STAMP(17);
   inv_level<8>(L, X, T, tid);
-  inv_level<16>(L, X, T, tid);
-  inv_level<32>(L, X, T, tid);
+  WV_STAMP(18);
+  inv_level_mma<16>(L, X, T, tid);
+  WV_STAMP(19);
+  inv_level_mma<32>(L, X, T, tid);
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* __restrict__ Mall, R* __restrict__ MTall,
+__global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, R* __restrict__ Mall, R* __restrict__ MTall,
                                                        double* __restrict__ logdet, int32_t* __restrict__ status,
                                                        int64_t Npad, int nblk, int slot0, int o) {
-  // LDS: L and X (64 x 65 each) + the compact inversion scratch: 76 KB in float64, so TWO workgroups share a CU
-  // (round 1 kept a third 64 x 65 array, 100 KB: one workgroup per CU, two passes over a 512-fit batch).
-  __shared__ R L[NB * DS];
-  __shared__ R X[NB * DS];
-  __shared__ R T[INV_SCRATCH];
-  __shared__ R colbuf[2][NB];
+  // LDS: L and X (64 x 65 each) + the inversion scratch + the panel buffers: 77 KB, so TWO workgroups
+  // share a CU (round 1 kept a third 64 x 65 array, 100 KB: one workgroup per CU, two passes over a 512-fit batch).
+  // Everything in here is float64 whatever the storage type R (float on a float32 context: the leaves are a sliver
+  // of the arithmetic, and the diagonal blocks are where a float32 factorisation loses its digits first).
+  using W = double;
+  __shared__ W L[NB * DS];
+  __shared__ W X[NB * DS];
+  __shared__ W T[INV_SCRATCH];
+  __shared__ W pbuf[NB * 4];
+  __shared__ W dinfo[16 * DINFO];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
   const int64_t mat = Npad * Npad;
@@ -279,18 +424,20 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
   R* M = Mall + (int64_t)b * mat;
   R* MT = MTall + (int64_t)b * mat;
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int lane = tid & 63, wr = tid >> 7, wc = (tid >> 6) & 1;  // the four waves as 2 x 2 quadrants of 32 x 32
   const int64_t o1 = o, o2 = o + NB;
   if (tid == 0) bad = 0;
 
-  auto stage_L_and_logdet = [&](R (&a)[4][4], bool anybad, int blk) {  // L -> LDS (upper zeroed), log-det partial
+  auto stage_L_and_logdet = [&](W (&a)[4][4], bool anybad, int blk) {  // L -> LDS (upper zeroed), log-det partial
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int i = 4 * ty + r, jc = 4 * tx + c;
-        L[i * DS + jc] = (jc <= i) ? a[r][c] : R(0);
+        L[i * DS + jc] = (jc <= i) ? a[r][c] : W(0);
       }
     if (anybad) bad = 1;  // (same value from every writer)
+    diag_inverses<W>(dinfo, X, tid);  // (dinfo is complete: factor64b's last barrier is behind every thread)
     __syncthreads();
     if (tid < 64) {
       double v = log((double)L[tid * DS + tid]);
@@ -303,22 +450,37 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * ty + r;
-      const R v[4] = {X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1], X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]};
+      const R v[4] = {(R)X[i * DS + 4 * tx], (R)X[i * DS + 4 * tx + 1], (R)X[i * DS + 4 * tx + 2], (R)X[i * DS + 4 * tx + 3]};
       st4(M + (row0 + i) * Npad + col0 + 4 * tx, v);
-      const R w[4] = {X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i], X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]};
+      const R w[4] = {(R)X[(4 * tx) * DS + i], (R)X[(4 * tx + 1) * DS + i], (R)X[(4 * tx + 2) * DS + i],
+                      (R)X[(4 * tx + 3) * DS + i]};
       st4(MT + (col0 + i) * Npad + row0 + 4 * tx, w);
     }
   };
 
   // ---- A11: factor, invert -> M11 ----
-  R a[4][4];
+  auto load_block = [&](int64_t row0, int64_t col0, W (&dst)[4][4]) {  // this thread's 4 x 4 of K[row0.., col0..]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ld4(K + (o1 + 4 * ty + r) * Npad + o1 + 4 * tx, a[r]);
+    for (int r = 0; r < 4; ++r) {
+      R v[4];
+      ld4(K + (row0 + 4 * ty + r) * Npad + col0 + 4 * tx, v);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[r][c] = (W)v[c];
+    }
+  };
+  W a[4][4];
+  WV_STAMP(0);
+  load_block(o1, o1, a);
   for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
-  bool anybad = factor64<R>(a, colbuf, ty, tx);
+  WV_STAMP(1);
+  bool anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
+  WV_STAMP(2);
   stage_L_and_logdet(a, anybad, o / NB);
-  invert64<R>(L, X, T, tid);  // X = M11
+  WV_STAMP(3);
+  invert64<W>(L, X, T, tid);  // X = M11
+  WV_STAMP(4);
   write_inverse_block(o1, o1);
+  WV_STAMP(5);
 
   // ---- S = A21 M11'  (A21 staged in L - L11 is dead once M11 and its log-det exist; M11 lower: k <= column) ----
 #pragma unroll
@@ -326,104 +488,73 @@ __global__ __launch_bounds__(256) void potrf128_kernel(R* __restrict__ Kall, R* 
     R v[4];
     ld4(K + (o2 + 4 * ty + r) * Npad + o1 + 4 * tx, v);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = v[c];
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = (W)v[c];
   }
+  load_block(o2, o2, a);  // A22, used after the products
   __syncthreads();
-  R sacc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sacc[r][c] = 0;
-  for (int k = 0; k < 4 * tx + 4; ++k) {
-    R ar[4], mc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ar[r] = L[(4 * ty + r) * DS + k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) mc[c] = X[(4 * tx + c) * DS + k];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) sacc[r][c] += ar[r] * mc[c];
-  }
+  double acc[2][2][4];
+  mma_zero(acc);
+  wave_mma<2, 2, 4, false, true>(acc, L + 32 * wr * DS, DS, X + 32 * wc * DS, DS, 0, 32 * wc + 32, 0, lane);
   __syncthreads();  // every read of L (A21) is done
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = sacc[r][c];  // L now holds S
+  mma_store(acc, L + 32 * wr * DS + 32 * wc, DS, 1.0, 0, lane);  // L now holds S
   __syncthreads();
+  WV_STAMP(6);
 
-  // ---- A22 -= S S'  and  T2 = S M11 (kept in registers) ----
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ld4(K + (o2 + 4 * ty + r) * Npad + o2 + 4 * tx, a[r]);
-  R t2[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) t2[r][c] = 0;
-  for (int k = 0; k < NB; ++k) {
-    R sr[4], sc[4], mk[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sr[r] = L[(4 * ty + r) * DS + k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sc[c] = L[(4 * tx + c) * DS + k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) mk[c] = X[k * DS + 4 * tx + c];  // M11[k][col] (zero above the diagonal)
+  // ---- T2 = S M11 (kept in registers; M11 lower: k >= column) and the Schur product S S' (lower quadrants) ----
+  double t2[2][2][4];
+  mma_zero(t2);
+  wave_mma<2, 2, 4, false, false>(t2, L + 32 * wr * DS, DS, X + 32 * wc, DS, 32 * wc, NB, 0, lane);
+  mma_zero(acc);
+  if (wr >= wc) wave_mma<2, 2, 4, false, true>(acc, L + 32 * wr * DS, DS, L + 32 * wc * DS, DS, 0, NB, 0, lane);
+  __syncthreads();  // S and M11 are no longer needed in LDS
+  if (wr >= wc) mma_store(acc, X + 32 * wr * DS + 32 * wc, DS, 1.0, 0, lane);  // staged in X for the 4 x 4 layout
+  __syncthreads();
+  if (ty >= tx) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[r][c] -= sr[r] * sc[c];
-        t2[r][c] += sr[r] * mk[c];
-      }
+      for (int c = 0; c < 4; ++c) a[r][c] -= X[(4 * ty + r) * DS + 4 * tx + c];
   }
-  __syncthreads();  // S and M11 are no longer needed in LDS
+  __syncthreads();
+  WV_STAMP(7);
 
   // ---- Schur complement: factor, invert -> M22 ----
   for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
-  anybad = factor64<R>(a, colbuf, ty, tx);
+  anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
+  WV_STAMP(8);
   stage_L_and_logdet(a, anybad, o / NB + 1);
-  invert64<R>(L, X, T, tid);  // X = M22
+  WV_STAMP(9);
+  invert64<W>(L, X, T, tid);  // X = M22
+  WV_STAMP(10);
   write_inverse_block(o2, o2);
   if (tid == 0 && bad) status[b] = 1;
+  WV_STAMP(11);
 
   // ---- M21 = -M22 T2  (T2 staged in L - L22 is dead after the inversion; M22 lower: k <= row) ----
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = t2[r][c];
+  mma_store(t2, L + 32 * wr * DS + 32 * wc, DS, 1.0, 0, lane);
   __syncthreads();
-  R macc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) macc[r][c] = 0;
-  for (int k = 0; k < 4 * ty + 4; ++k) {
-    R mr[4], tc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mr[r] = X[(4 * ty + r) * DS + k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) tc[c] = L[k * DS + 4 * tx + c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) macc[r][c] -= mr[r] * tc[c];
-  }
-  // M21 -> M[(o2 + i)][o1 + j] and M'[(o1 + j)][o2 + i]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) st4(M + (o2 + 4 * ty + r) * Npad + o1 + 4 * tx, macc[r]);
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = macc[r][c];  // stage for the transposed store
+  mma_zero(acc);
+  wave_mma<2, 2, 4, false, false>(acc, X + 32 * wr * DS, DS, L + 32 * wc, DS, 0, 32 * wr + 32, 0, lane);
+  __syncthreads();  // every read of T2 is done: L becomes the staging image of M21
+  mma_store(acc, L + 32 * wr * DS + 32 * wc, DS, -1.0, 0, lane);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int j = 4 * ty + r;  // row of M' block = column of M21
-    const R w[4] = {L[(4 * tx) * DS + j], L[(4 * tx + 1) * DS + j], L[(4 * tx + 2) * DS + j], L[(4 * tx + 3) * DS + j]};
-    st4(MT + (o1 + j) * Npad + o2 + 4 * tx, w);
+    const int i = 4 * ty + r;  // row of M21 for the direct store, row of M' block = column of M21 for the other
+    const R v[4] = {(R)L[i * DS + 4 * tx], (R)L[i * DS + 4 * tx + 1], (R)L[i * DS + 4 * tx + 2], (R)L[i * DS + 4 * tx + 3]};
+    st4(M + (o2 + i) * Npad + o1 + 4 * tx, v);
+    const R w[4] = {(R)L[(4 * tx) * DS + i], (R)L[(4 * tx + 1) * DS + i], (R)L[(4 * tx + 2) * DS + i],
+                    (R)L[(4 * tx + 3) * DS + i]};
+    st4(MT + (o1 + i) * Npad + o2 + 4 * tx, w);
   }
+  WV_STAMP(12);
 }
+
+#ifdef WV_STAMPS
+extern "C" __attribute__((visibility("default"))) int wv_dbg_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wv_stamps), sizeof(wv_stamps));
+}
+#endif
 
 void launch_potrf128(Problem& p, hipStream_t st, int slot0, int nb, int o) {
   p.timer.begin(st, ST_POTRF_DIAG);
@@ -828,51 +959,19 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 //   M21 = -M22 T                      (contraction k <= row)
 // L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
 // ---------------------------------------------------------------------------------------
-// Tile width for a product with a rows x cols output over nb matrices: 128-wide tiles unless so few of them
-// exist that most of the 512 resident workgroup slots would idle - then 64-wide tiles double the parallelism
-// (the small-batch, large-N end: the tail of a job, a single fit).  WV_BN_FILL=0 restores 128 everywhere.
+// Tile for a product with a rows x cols output over nb matrices (launch_gemm's tile code): 128 x 128 unless so few
+// tiles exist that most of the 512 resident workgroup slots would idle - then 128 x 64 (twice the workgroups), and
+// when even those number fewer than 256, i.e. one per CU, the small 64 x 64 tile (four times).  That is the
+// small-batch, large-N end: the tail of a job, a single fit.  WV_BN_FILL=0 restores 128 everywhere; WV_SMALL_FILL=0
+// stops at 128 x 64.
 static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
-  if (cols <= 64) return 64;
   static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 512; }();
+  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 256; }();
   int64_t tiles = ((rows + 127) / 128) * ((cols + 127) / 128);
   if (lower_only) tiles = (tiles + (rows + 127) / 128) / 2;
-  return tiles * nb < fill ? 64 : 128;
-}
-
-// ---- side lane: T = S M11 beside the critical path when few fits are in flight ----
-static SideLane* side_lane(Problem& p, hipStream_t st, int nb) {
-  static const int max_nb = [] { const char* e = getenv("WV_SIDE_T"); return e ? atoi(e) : 8; }();
-  if (nb > max_nb || p.Npad < 512) return nullptr;  // full batches fill the GPU from one stream
-  for (auto& l : p.lanes)
-    if (l.main == st) return &l;
-  SideLane l;
-  l.main = st;
-  if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  if (p.lanes.capacity() < 16) p.lanes.reserve(16);  // (pointers into the vector are held across the recursion)
-  if (p.lanes.size() >= 16) {
-    hipStreamDestroy(l.side);
-    return nullptr;
-  }
-  p.lanes.push_back(l);
-  return &p.lanes.back();
-}
-static hipEvent_t lane_event(SideLane& l) {
-  if (l.next == l.events.size()) {
-    hipEvent_t e;
-    hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    l.events.push_back(e);
-  }
-  return l.events[l.next++];
-}
-// the main stream must not overwrite the S scratch, or read T's output, before the side product is done
-static void lane_join(SideLane* l) {
-  if (l && l->pending) {
-    hipStreamWaitEvent(l->main, l->pending, 0);
-    l->pending = nullptr;
-  }
+  if (tiles * nb >= fill) return cols <= 64 ? 64 : 128;
+  if (2 * tiles * nb >= small_fill) return 64;
+  return 32;
 }
 
 template <typename R>
@@ -895,8 +994,6 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();  // holds S' (h1 x h2): K-strided image of S
   const int64_t sS = p.pbuf_elems();
   fi_node<R>(p, st, slot0, nb, o, h1);
-  SideLane* lane = side_lane(p, st, nb);
-  lane_join(lane);  // an ancestor's T may still be reading the S scratch this node is about to overwrite
   {  // S = A21 * M11'   written transposed;  B(n, k) = M11[n][k] = MT[k][n]  (K-strided)
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = K0 + (o + h1) * Np + o;
@@ -909,42 +1006,42 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     p.timer.work(ST_CHOL_TRSM, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   }
-  hipStream_t st_t = st;  // the stream T runs on
-  if (lane) {
-    hipEvent_t s_done = lane_event(*lane);
-    hipEventRecord(s_done, st);
-    hipStreamWaitEvent(lane->side, s_done, 0);
-    st_t = lane->side;
+  // A22 -= S S'   with A(m, k) = S'[k][m], B(n, k) = S'[k][n]
+  GemmArgsT<R> su = base_args<R>(p, slot0, nb);
+  su.A = S0; su.B = S0; su.sA = su.sB = sS; su.lda = su.ldb = (int)h2;
+  su.C = K0 + (o + h1) * Np + (o + h1);
+  su.M = (int)h2; su.N = (int)h2; su.kb = 0; su.ke = (int)h1;
+  su.alpha = -1.0; su.beta = 1.0; su.tri = 1; su.tag = 2;
+  // T = S * M11 over the dead A21 block;  A(m, k) = S'[k][m],  B(n, k) = M11[k][n].  Off the critical path: only
+  // M21, after the whole right child, reads it.
+  GemmArgsT<R> tp = base_args<R>(p, slot0, nb);
+  tp.A = S0; tp.sA = sS; tp.lda = (int)h2;
+  tp.B = M0 + o * Np + o;
+  tp.C = K0 + (o + h1) * Np + o;
+  tp.M = (int)h2; tp.N = (int)h1; tp.kb = 0; tp.ke = (int)h1; tp.klo_mode = 2;
+  const int tile_su = pick_bn(h2, h2, nb, true), tile_tp = pick_bn(h2, h1, nb, false);
+  bool paired = false;
+  if constexpr (std::is_same<R, double>::value) {
+    // few fits in flight (both products on 64-wide or small tiles): ONE launch runs them side by side
+    static const bool pair_ok = [] { const char* e = getenv("WV_PAIR"); return e ? atoi(e) != 0 : true; }();
+    if (pair_ok && tile_su <= 64 && tile_tp <= 64) {
+      p.timer.begin(st, ST_CHOL_TRAIL);
+      launch_gemm_pair(st, su, tp, std::min(tile_su, tile_tp));
+      p.timer.end(st);
+      paired = true;
+    }
   }
-  {  // A22 -= S S'   with A(m, k) = S'[k][m], B(n, k) = S'[k][n]
-    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
-    a.A = S0; a.B = S0; a.sA = a.sB = sS; a.lda = a.ldb = (int)h2;
-    a.C = K0 + (o + h1) * Np + (o + h1);
-    a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
-    a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.tag = 2;
+  if (!paired) {
     p.timer.begin(st, ST_CHOL_TRAIL);
-    launch_gemm(st, a, false, false, pick_bn(h2, h2, nb, true));
+    launch_gemm(st, su, false, false, tile_su);
     p.timer.end(st);
-    p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
+    p.timer.begin(st, ST_TRTRI_A);
+    launch_gemm(st, tp, false, false, tile_tp);
+    p.timer.end(st);
   }
-  {  // T = S * M11 over the dead A21 block;  A(m, k) = S'[k][m],  B(n, k) = M11[k][n]
-    GemmArgsT<R> a = base_args<R>(p, slot0, nb);
-    a.A = S0; a.sA = sS; a.lda = (int)h2;
-    a.B = M0 + o * Np + o;
-    a.C = K0 + (o + h1) * Np + o;
-    a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.klo_mode = 2;
-    p.timer.begin(st_t, ST_TRTRI_A);
-    launch_gemm(st_t, a, false, false, pick_bn(h2, h1, nb, false));
-    p.timer.end(st_t);
-    p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
-  }
-  if (lane) {
-    hipEvent_t t_done = lane_event(*lane);
-    hipEventRecord(t_done, lane->side);
-    lane->pending = t_done;  // joined by the next S that overwrites the scratch, at the latest before M21 below
-  }
+  p.timer.work(ST_CHOL_TRAIL, nb * (double)h1 * (double)h2 * (h2 + NB), 0.0);
+  p.timer.work(ST_TRTRI_A, nb * (double)h2 * h1 * (h1 + NB), 0.0);
   fi_node<R>(p, st, slot0, nb, o + h1, h2);
-  lane_join(lane);
   {  // M21 = -M22 * T  (also written transposed into MT);  A(m, k) = M22[m][k] = MT[k][m]
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = MT0 + (o + h1) * Np + (o + h1);
@@ -1032,13 +1129,11 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
 }
 
 void factor_value_only(Problem& p, hipStream_t st, int slot0, int nb) {
-  if (SideLane* l = side_lane(p, st, nb)) l->next = 0;
   if (p.f32) fv_node<float>(p, st, slot0, nb, 0, p.Npad);
   else fv_node<double>(p, st, slot0, nb, 0, p.Npad);
 }
 
 void factor_inverse(Problem& p, hipStream_t st, int slot0, int nb) {
-  if (SideLane* l = side_lane(p, st, nb)) l->next = 0;  // (events of the previous evaluation are all consumed)
   if (p.f32) fi_node<float>(p, st, slot0, nb, 0, p.Npad);
   else fi_node<double>(p, st, slot0, nb, 0, p.Npad);
 }
@@ -1054,8 +1149,9 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
   p.timer.begin(st, ST_LAUUM);
-  // (always 128-wide tiles: one launch per evaluation, and it keeps this product on its own kernel symbol)
-  launch_gemm(st, a, false, false, Np > 64 ? 128 : 64);
+  // 128-wide tiles (its own kernel symbols: off-diagonal + diagonal-tile launch) unless so few fits are in flight
+  // that the two dependent launches and their few long tiles are the cost: then 64-wide tiles, one launch
+  launch_gemm(st, a, false, false, pick_bn(Np, Np, nb, true));
   p.timer.end(st);
   p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
 }

@@ -192,7 +192,7 @@ int32_t wv_dbg_gemm(wv_ctx* ctx, const double* A, const double* B, double* C, in
                     int32_t K, int32_t a_kc, int32_t b_kc, int32_t bn, double alpha, double beta,
                     int32_t nbatch) {
   if (!ctx || !A || !B || !C || M < 2 || N < 2 || K < 16 || (K % 16) || (M % 2) || (N % 2) ||
-      (bn != 64 && bn != 128) || nbatch < 1) {
+      (bn != 32 && bn != 64 && bn != 128) || nbatch < 1) {  // (32: launch_gemm's code for the small 64 x 64 tile)
     set_error("wv_dbg_gemm: bad argument");
     return WV_E_BADARG;
   }

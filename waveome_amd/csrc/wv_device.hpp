@@ -135,17 +135,6 @@ struct Group {
   int32_t* h_spec = nullptr;   // [nslots] structure index of each slot's task (multi-structure problems)
 };
 
-// A second stream beside a group's main stream for the one product of a recursion node that is off the
-// critical path (T = S M11, needed only by M21 after the whole right child): with few fits in flight the GPU is
-// latency- not throughput-bound, and T then runs beside the Schur complement update and the start of the right
-// child instead of in front of them (wv_chol.hip, fi_node).
-struct SideLane {
-  hipStream_t main = nullptr, side = nullptr;
-  std::vector<hipEvent_t> events;  // recycled per evaluation
-  size_t next = 0;
-  hipEvent_t pending = nullptr;    // completion of a T that still reads the S scratch / has not been waited for
-};
-
 struct Problem {
   Ctx* ctx = nullptr;
   Spec spec;      // structure 0 (the only one of a single-structure problem)
@@ -180,7 +169,6 @@ struct Problem {
   int32_t *dcol = nullptr, *dstatus = nullptr;
   int64_t workspace_bytes = 0;
   std::vector<Group> groups;
-  std::vector<SideLane> lanes;
   StageTimer timer;
   int64_t pbuf_elems() const { int64_t h = Npad / 2 + NB; return std::max<int64_t>(h * h, Npad * NB); }
   int nblk() const { return (int)(Npad / NB); }
@@ -199,6 +187,7 @@ void launch_trmv(Problem& p, hipStream_t st, const double* Tmat, const double* i
                  int nb, bool trans);
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0);
 void launch_gemm(hipStream_t st, const GemmArgs& a, bool a_kcontig, bool b_kcontig, int bn);
+void launch_gemm_pair(hipStream_t st, const GemmArgs& a0, const GemmArgs& a1, int tile);  // two products, one launch
 void launch_gemm(hipStream_t st, const GemmArgsF& a, bool a_kcontig, bool b_kcontig, int bn);
 void launch_resid(Problem& p, hipStream_t st, int slot0, int nb);
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha);

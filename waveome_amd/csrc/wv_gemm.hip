@@ -117,13 +117,19 @@ __device__ inline void mma_chunk_diag(double (&acc)[4][NJ][4], const double* __r
 // TOUT: 0 = write C; 1 = write only C' (to g.CT, leading dimension g.ldct); 2 = write both.
 // The transposed copy keeps later products on the K-strided (fastest) load path.
 // TAG only gives a launch its own symbol so that profilers report it separately: 1 = K_y^-1 = M'M,
-// 2 = the Cholesky trailing update A22 -= S S'.
+// 2 = the Cholesky trailing update A22 -= S S'.  TAG bit 4 (16): the SMALL tile of the few-fits regime - block tile
+// 64 x 64, the four waves side by side (64 x 16 each): four times the workgroups of a 128 x 128 tiling, for products
+// whose larger tiles would leave most of the 256 CUs idle (one fit in flight: every product of the recursion).
 template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT, int TAG = 0>
-__global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
+  constexpr bool SMALL = (TAG & 16) != 0;
+  static_assert(!SMALL || BN == 64, "the small tile is 64 x 64");
+  constexpr int BM = SMALL ? 64 : wv::BM;   // block tile rows (shadows the 128 of the regular tiling)
+  constexpr int WCOLS = SMALL ? BN / 4 : BN / 2;  // columns of a wave's sub-tile (its rows: 64)
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
   constexpr bool NOLDS = (TAG & 8) != 0;  // timing experiment only: fragments are constants, no LDS reads in the K loop
-  constexpr int NJ = BN / 32;  // B fragments per wave
+  constexpr int NJ = WCOLS / 16;  // B fragments per wave
   // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
   // image of half the C tile in the epilogue
   constexpr int LDC = BN + 2;
@@ -138,13 +144,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   const int tiles = g.tiles_live;
   int b, tile;
   if (g.nbatch >= 8) {
-    int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    int xcd = bid & 7, q = bid >> 3;
     b = xcd + 8 * (q / tiles);
     tile = q % tiles;
     if (b >= g.nbatch) return;
   } else {
-    b = blockIdx.x / tiles;
-    tile = blockIdx.x % tiles;
+    b = bid / tiles;
+    tile = bid % tiles;
   }
   // longest contraction first: ranges trimmed from above (khi_mode) grow with the tile index
   if (g.khi_mode && !g.tri) tile = tiles - 1 - tile;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   double* __restrict__ C = g.C + (int64_t)b * g.sC;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = SMALL ? 0 : wave >> 1, wn = SMALL ? wave : wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
   // B-fragment column (within its 16) for rotation s: 4*((blk + s) & 3) + j
   const int fblk = (lane >> 2) & 3, fj = lane & 3;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   // (40 of 64 MFMAs per k-step) and the wave whose own block lies above the diagonal takes over the right 32
   // columns of the full block (32 MFMAs each): no partial sums to merge.  (ewm, ewn) = the 64 x 64 block a wave
   // works on, ecol = its first column inside that block, half = it owns 32 columns only.
-  constexpr bool TRIOPT = (TAG & 4) != 0 && BN == 128 && TOUT == 0;
+  constexpr bool TRIOPT = (TAG & 4) != 0 && BN == 128 && TOUT == 0 && !SMALL;
   int ewm = wm, ewn = wn, ecol = 0;
   bool half = false;
   if (TRIOPT && wm != wn) {
@@ -230,11 +236,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   // co-resident workgroup.
   int wkb = kb, wke = ke;
   {
-    const int wr = m0 + ewm * 64, wc = n0 + ewn * (BN / 2);
+    const int wr = m0 + ewm * 64, wc = n0 + ewn * WCOLS;
     if (g.klo_mode == 1) wkb = max(wkb, wr + g.koff);
     if (g.klo_mode == 2) wkb = max(wkb, wc + g.koff);
     if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
-    if (g.khi_mode == 2) wke = min(wke, wc + BN / 2 + g.koff);
+    if (g.khi_mode == 2) wke = min(wke, wc + WCOLS + g.koff);
     if (g.tri && !TRIOPT && wc + g.tri_off > wr + 63) wke = wkb;  // nothing to do
   }
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
     if (kc0 >= wkb && kc0 < wke && !(g.prio & 8)) {
       if constexpr (TRIOPT) {
         if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
-        else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * (BN / 2), brot, fr, fk);
+        else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * WCOLS, brot, fr, fk);
       } else {
 #pragma unroll OCC == 1 ? 4 : 1
         for (int s = 0; s < KC / 4; ++s) {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
           for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * (BN / 2) + j * 16 + brot[r], s * 4 + fk)];
+              const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * WCOLS + j * 16 + brot[r], s * 4 + fk)];
 #pragma unroll
               for (int i = 0; i < 4; ++i)
                 acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   constexpr int PAIRS = BN / 2;             // double2 per row
   constexpr int NROWIT = 64 * PAIRS / 256;  // row-pieces per thread per half
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < BM / 64; ++h) {
     // issue this half's C reads first: their latency hides behind the LDS staging and the barrier
     d2 cv[NROWIT];
     if (beta != 0.0) {
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
           if (TRIOPT && half && j >= NJ / 2) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            smem[(i * 16 + 4 * fblk + fk) * LDC + ewn * (BN / 2) + ecol + j * 16 + brot[r]] = alpha * acc[i][j][r];
+            smem[(i * 16 + 4 * fblk + fk) * LDC + ewn * WCOLS + ecol + j * 16 + brot[r]] = alpha * acc[i][j][r];
         }
     }
     __syncthreads();
@@ -373,20 +379,32 @@ __global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
   }
 }
 
-void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int bn) {
-  if (bn != 64 && bn != 128) {
-    fail_launch("launch_gemm: tile width must be 64 or 128");
-    return;
-  }
-  GemmArgs a = a_in;
+template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT, int TAG = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_f64_kernel(GemmArgs g) {
+  gemm_body<A_KC, B_KC, BN, OCC, TOUT, TAG>(g, blockIdx.x);
+}
+
+// Two independent products of the same operand layout in ONE launch: workgroups [0, n0) work on g0, the rest on g1.
+// The recursion's trailing update A22 -= S S' and T = S M11 both only need S; with few fits in flight neither
+// fills the GPU, and a launch of both costs no stream events (an event record / wait pair between two streams
+// measured ~6.5 us each on the critical path) and one launch less.
+template <bool A_KC, bool B_KC, int BN, int OCC, int TOUT, int TAG = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_f64_pair_kernel(GemmArgs g0, GemmArgs g1, int n0) {
+  const bool first = (int)blockIdx.x < n0;
+  const GemmArgs* g = first ? &g0 : &g1;
+  gemm_body<A_KC, B_KC, BN, OCC, TOUT, TAG>(*g, first ? (int)blockIdx.x : (int)blockIdx.x - n0);
+}
+
+// Tile counts, launch-order switches and the grid size of one product; 0 workgroups = nothing to launch, -1 = refused.
+static int prepare_gemm(GemmArgs& a, int BM, int bn) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + bn - 1) / bn;
-  if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
+  if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return 0;
   // the kernel walks the contraction in chunks of KC = 16 from 16-aligned offsets (Npad is a multiple of 64, so
   // every schedule in wv_chol.hip satisfies this); anything else would silently drop a remainder
   if ((a.ke - a.kb) % KC != 0 || a.kb % KC != 0 || a.koff % KC != 0) {
     fail_launch("launch_gemm: contraction range / offset not a multiple of 16");
-    return;
+    return -1;
   }
   int tiles = a.tiles_m * a.tiles_n;
   if (a.tri) {
@@ -412,8 +430,47 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     if (rt < 0) { const char* e = getenv("WV_ROT_TRI"); rt = e ? atoi(e) : 0; }
     a.rot_tri = rt;
   }
-  if (tiles <= 0) return;
-  int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
+  if (tiles <= 0) return 0;
+  return (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
+}
+
+// Both products K-strided x K-strided with plain output (the layout of A22 -= S S' and T = S M11); tile code 32 or 64.
+void launch_gemm_pair(hipStream_t st, const GemmArgs& a0_in, const GemmArgs& a1_in, int tile) {
+  if (tile != 32 && tile != 64) {
+    fail_launch("launch_gemm_pair: tile code must be 32 or 64");
+    return;
+  }
+  GemmArgs a0 = a0_in, a1 = a1_in;
+  if (a0.tout != 0 || a1.tout != 0) {
+    fail_launch("launch_gemm_pair: plain outputs only");
+    return;
+  }
+  const int bm = tile == 32 ? 64 : wv::BM;
+  const int n0 = prepare_gemm(a0, bm, 64), n1 = prepare_gemm(a1, bm, 64);
+  if (n0 < 0 || n1 < 0) return;
+  if (n0 == 0 || n1 == 0) {  // (degenerate: one product is empty)
+    if (n0 > 0) launch_gemm(st, a0_in, false, false, tile);
+    if (n1 > 0) launch_gemm(st, a1_in, false, false, tile);
+    return;
+  }
+  const dim3 g(n0 + n1), blk(256);
+  if (tile == 32) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, false, 64, 2, 0, 16>), g, blk, 0, st, a0, a1, n0);
+  else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, false, 64, 2, 0, 0>), g, blk, 0, st, a0, a1, n0);
+}
+
+// `tile`: 128 = block tile 128 x 128, 64 = 128 x 64, 32 = the small 64 x 64 tile (few fits in flight)
+void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int tile) {
+  if (tile != 32 && tile != 64 && tile != 128) {
+    fail_launch("launch_gemm: tile code must be 32, 64 or 128");
+    return;
+  }
+  const bool small = tile == 32;
+  const int bn = small ? 64 : tile;
+  const int BM = small ? 64 : wv::BM;  // (shadows the regular 128 in the tile counts below)
+  GemmArgs a = a_in;
+  const int grid = prepare_gemm(a, BM, bn);
+  if (grid <= 0) return;
+  const int tiles = a.tiles_live;
   dim3 g(grid), blk(256);
   static int occ = -1;
   if (occ < 0) {
@@ -422,6 +479,14 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   }
   if ((a.prio & 32) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // (timing experiment)
     hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 8>), g, blk, 0, st, a);
+    return;
+  }
+  if (small) {  // the three operand layouts of the recursion (S, trailing update / T / M'M, M21) and the NT form
+    if (a.tout == 1 && a_kc && !b_kc) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 64, 2, 1, 16>), g, blk, 0, st, a);
+    else if (a.tout == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 64, 2, 2, 16>), g, blk, 0, st, a);
+    else if (a.tout == 0 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 64, 2, 0, 16>), g, blk, 0, st, a);
+    else if (a.tout == 0 && a_kc && b_kc) hipLaunchKernelGGL((gemm_f64_kernel<true, true, 64, 2, 0, 16>), g, blk, 0, st, a);
+    else fail_launch("launch_gemm: operand layout not built for the small tile");
     return;
   }
   if ((a.tag == 1 || a.tag == 2) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {

@@ -330,7 +330,14 @@ int Lbfgs::finish_iteration() {
   if (nfev_ > o_.maxfun) return WV_LB_STOP_MAXFUN;
   if (sbgnrm_ <= o_.gtol) return WV_LB_CONV_GTOL;
   double ddum = std::max({std::fabs(fold_), std::fabs(f_), 1.0});
-  if ((fold_ - f_) <= o_.ftol * ddum) return WV_LB_CONV_FTOL;
+  if ((fold_ - f_) <= o_.ftol * ddum) {
+    // A noisy objective (float32 contexts) can fake this test far from the optimum: only the
+    // (ftol_patience_ + 1)-th hit in a row stops; until then the iteration goes on as if the test had passed.
+    if (ftol_strikes_ >= ftol_patience_) return WV_LB_CONV_FTOL;
+    ++ftol_strikes_;
+  } else {
+    ftol_strikes_ = 0;
+  }
   // BFGS pair: y = g - gold, s = stp * d
   double dr, dd;
   if (stp_ == 1.0) {

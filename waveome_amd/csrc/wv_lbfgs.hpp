@@ -49,6 +49,9 @@ class Lbfgs {
   int n_eval() const { return nfev_; }
   double f() const { return f_; }
   int n() const { return n_; }
+  // float32 contexts only (the float64 path keeps SciPy's rule exactly): how many consecutive hits of the
+  // relative-decrease test are passed over before one counts as "converged"
+  void set_ftol_patience(int k) { ftol_patience_ = k; }
 
  private:
   void direction();        // d = -H g
@@ -65,6 +68,7 @@ class Lbfgs {
   // f_ starts at +inf: a fit whose very first evaluation is non-finite must not report a finite loss
   double f_ = std::numeric_limits<double>::infinity(), fold_ = 0, gd_ = 0, gdold_ = 0, stp_ = 0, dnorm_ = 0, sbgnrm_ = 0;
   int iter_ = 0, nfev_ = 0, ifun_ = 0, iback_ = 0;
+  int ftol_patience_ = 0, ftol_strikes_ = 0;
   bool first_ = true, in_ls_ = false;
   double bis_lo_ = 0;  // non-finite handling: last finite step on the ray
   bool had_nonfinite_ = false;
