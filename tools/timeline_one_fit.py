@@ -1,6 +1,7 @@
 """Launch-bound regime, seen launch by launch.
   run:        rocprofv3 --kernel-trace -d DIR -o tl -- python3 tools/timeline_one_fit.py run N [fits]
   summarise:  python3 tools/timeline_one_fit.py sum DIR/…_kernel_trace.csv > profiles/rNN_timeline_one_fit_N.txt
+  list:       python3 tools/timeline_one_fit.py seq DIR/…_kernel_trace.csv    (every launch: start, duration, workgroups)
 `run` does a few value+gradient evaluations of the headline kernel with `fits` (default 1) fits in flight; `sum` takes
 the LAST evaluation in the trace (from its feature_kernel launch on) and prints, per kernel symbol, launches, time inside
 kernels and the idle time in front of them (start minus the latest end so far, clamped at 0: overlap with the side
@@ -33,14 +34,25 @@ def short(name):
     return n.replace("(anonymous namespace)::", "")
 
 
-def summarise(path):
+def last_evaluation(path):
     rows = []
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]),
+                         int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) * int(r["Grid_Size_Y"])))
     rows.sort()
     first = max(i for i, r in enumerate(rows) if r[2].startswith("feature_kernel"))
-    ev = rows[first:]
+    return rows[first:]
+
+
+def sequence(path):
+    ev = last_evaluation(path)
+    for s, e, n, wg in ev:
+        print(f"{(s - ev[0][0]) * 1e-3:9.1f} us  {(e - s) * 1e-3:7.1f} us  {wg:6d} wg  {n}")
+
+
+def summarise(path):
+    ev = [r[:3] for r in last_evaluation(path)]
     per = OrderedDict()
     horizon = ev[0][0]
     for s, e, n in ev:
@@ -60,5 +72,7 @@ def summarise(path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    elif sys.argv[1] == "seq":
+        sequence(sys.argv[2])
     else:
         summarise(sys.argv[2])

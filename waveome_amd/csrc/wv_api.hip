@@ -410,7 +410,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
             alloc((void**)&p.dfeat, sizeof(double) * 2 * std::max(1, p.max_feat) * Np * max_batch) &&
             alloc((void**)&p.dfconst, sizeof(double) * 4 * std::max(1, p.max_fact) * max_batch) &&
             alloc((void**)&p.dlogdet, sizeof(double) * p.nblk() * max_batch) &&
-            alloc((void**)&p.dpart, sizeof(double) * trace_nwg(p) * np * max_batch) &&
+            alloc((void**)&p.dpart, sizeof(double) * trace_part_stride(p) * np * max_batch) &&
             alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&
             alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
             alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
@@ -420,7 +420,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     return WV_E_OOM;
   }
   p.workspace_bytes = total;
-  const int nwg = trace_nwg(p);
+  const int nwg = trace_part_stride(p);
   WV_HIP_TRY(hipMemset(p.dX, 0, sizeof(double) * Np * D));
   WV_HIP_TRY(hipMemset(p.dY, 0, sizeof(double) * Np * P));
   if (p.f32) {

@@ -18,7 +18,9 @@
 namespace wv {
 
 constexpr int OUTER = 256;  // outer Cholesky block
-constexpr int DS = NB + 1;  // LDS row stride of the 64x64 diagonal block
+// LDS row stride of the 64 x 64 blocks: 66 = 2 mod 32 doubles keeps an MFMA fragment read of a row-major operand
+// (16 rows x 2 k per half-wave -> 2 row + k) free of bank conflicts; the column-wise reads are 2-way
+constexpr int DS = NB + 2;
 
 // ---------------------------------------------------------------------------------------
 // potrf_diag: factor the 64x64 diagonal block at (j0, j0) of every slot's Kbuf in LDS, write
@@ -490,7 +492,6 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = (W)v[c];
   }
-  load_block(o2, o2, a);  // A22, used after the products
   __syncthreads();
   double acc[2][2][4];
   mma_zero(acc);
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   mma_zero(t2);
   wave_mma<2, 2, 4, false, false>(t2, L + 32 * wr * DS, DS, X + 32 * wc, DS, 32 * wc, NB, 0, lane);
   mma_zero(acc);
+  load_block(o2, o2, a);  // A22 (its latency hides behind the product below)
   if (wr >= wc) wave_mma<2, 2, 4, false, true>(acc, L + 32 * wr * DS, DS, L + 32 * wc * DS, DS, 0, NB, 0, lane);
   __syncthreads();  // S and M11 are no longer needed in LDS
   if (wr >= wc) mma_store(acc, X + 32 * wr * DS + 32 * wc, DS, 1.0, 0, lane);  // staged in X for the 4 x 4 layout
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
                                                      const double* __restrict__ logdet,
                                                      const double* __restrict__ part,
                                                      double* __restrict__ out, int64_t N,
-                                                     int64_t Npad, int nblk, int nwg,
+                                                     int64_t Npad, int nblk, int nwg, int part_stride,
                                                      int out_stride, int slot0, int with_grad) {
   __shared__ double sh[4];
   const int b = slot0 + blockIdx.x, tid = threadIdx.x;
@@ -831,11 +833,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
     o[2] = ld;
   }
   if (with_grad) {
-    for (int p = tid; p < np; p += 256) {
+    // gradient = sum of the trace pass's per-workgroup partial sums: 16 parameters at a time, 16 threads per
+    // parameter striding over the workgroups (a single thread per parameter walking all nwg partials was a chain of
+    // dependent loads: 37 us at N = 2048, 131 us at N = 4096 with one fit in flight), then a fixed-order LDS sum
+    __shared__ double gsh[16][17];
+    const int pl = tid & 15, wl = tid >> 4;
+    for (int p0 = 0; p0 < np; p0 += 16) {
+      const int p = p0 + pl;
       double g = 0.0;
-      for (int w = 0; w < nwg; ++w) g += part[((int64_t)b * nwg + w) * np + p];
-      if (p == sp->mean_param) g = sa;
-      o[3 + p] = g;
+      if (p < np)
+        for (int w = wl; w < nwg; w += 16) g += part[((int64_t)b * part_stride + w) * np + p];
+      gsh[wl][pl] = g;
+      __syncthreads();
+      if (tid < 16 && p0 + tid < np) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += gsh[k][tid];
+        o[3 + p0 + tid] = (p0 + tid == sp->mean_param) ? sa : t;
+      }
+      __syncthreads();
     }
   }
 }
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
 void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad) {
   p.timer.begin(st, ST_REDUCE);
   hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dslotspec, p.dz, p.dalpha, p.dlogdet,
-                     p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p), p.out_stride, slot0,
+                     p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p, nb), trace_part_stride(p), p.out_stride, slot0,
                      with_grad ? 1 : 0);
   p.timer.end(st);
 }
@@ -960,13 +976,13 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 // L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
 // ---------------------------------------------------------------------------------------
 // Tile for a product with a rows x cols output over nb matrices (launch_gemm's tile code): 128 x 128 unless so few
-// tiles exist that most of the 512 resident workgroup slots would idle - then 128 x 64 (twice the workgroups), and
-// when even those number fewer than 256, i.e. one per CU, the small 64 x 64 tile (four times).  That is the
-// small-batch, large-N end: the tail of a job, a single fit.  WV_BN_FILL=0 restores 128 everywhere; WV_SMALL_FILL=0
-// stops at 128 x 64.
+// tiles exist that most of the 512 resident workgroup slots would idle - then the small 64 x 64 tile (four times the
+// workgroups; measured better than 128 x 64 wherever that was: WV_SMALL_FILL = 1024 leaves 128 x 64 no window).
+// That is the small-batch, large-N end: the tail of a job, a single fit.  WV_BN_FILL=0 restores 128 everywhere;
+// WV_SMALL_FILL=0 stops at 128 x 64.
 static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
   static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 512; }();
-  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 256; }();
+  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 1024; }();
   int64_t tiles = ((rows + 127) / 128) * ((cols + 127) / 128);
   if (lower_only) tiles = (tiles + (rows + 127) / 128) / 2;
   if (tiles * nb >= fill) return cols <= 64 ? 64 : 128;
@@ -1151,7 +1167,8 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   p.timer.begin(st, ST_LAUUM);
   // 128-wide tiles (its own kernel symbols: off-diagonal + diagonal-tile launch) unless so few fits are in flight
   // that the two dependent launches and their few long tiles are the cost: then 64-wide tiles, one launch
-  launch_gemm(st, a, false, false, pick_bn(Np, Np, nb, true));
+  static const int forced = [] { const char* e = getenv("WV_LAUUM_TILE"); return e ? atoi(e) : 0; }();  // (experiments)
+  launch_gemm(st, a, false, false, forced ? forced : pick_bn(Np, Np, nb, true));
   p.timer.end(st);
   p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
 }

@@ -193,7 +193,8 @@ void launch_resid(Problem& p, hipStream_t st, int slot0, int nb);
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha);
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb);
 void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad);
-int trace_nwg(const Problem& p);
+int trace_nwg(const Problem& p, int nb);
+int trace_part_stride(const Problem& p);
 
 // schedules
 void cholesky(Problem& p, hipStream_t st, int slot0, int nb);

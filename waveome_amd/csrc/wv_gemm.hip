@@ -494,7 +494,11 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     // Their diagonal tiles go to a second launch whose waves share the three needed 64 x 64 blocks evenly
     // (TRIOPT in the kernel): trailing update -6.5 %, M'M -2 % at N = 2048.  WV_TRI_SPLIT=0: one launch.
     static const bool split = [] { const char* e = getenv("WV_TRI_SPLIT"); return e ? atoi(e) != 0 : true; }();
-    const bool can_split = split && a.tri == 1 && a.tri_off == 0 && a.M == a.N && a.tiles_m > 1 && a.M % BM == 0;
+    // (only when the diagonal launch - one workgroup per tile row and matrix - can fill the GPU by itself: with few
+    // fits in flight it is a serial tail of a few long tiles, 427 us of 1.19 ms at N = 4096 with one fit)
+    static const int split_min = [] { const char* e = getenv("WV_TRI_SPLIT_MIN"); return e ? atoi(e) : 256; }();
+    const bool can_split = split && a.tri == 1 && a.tri_off == 0 && a.M == a.N && a.tiles_m > 1 && a.M % BM == 0 &&
+                           a.nbatch * a.tiles_m >= split_min;
     GemmArgs o = a;
     if (can_split) {
       o.tri = 3;

@@ -427,7 +427,8 @@ __device__ inline void tri_decode(int t, int& ti, int& tj) {
   tj = t - i * (i + 1) / 2;
 }
 
-constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup)
+constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup) ...
+constexpr int FEW_FITS = 8;  // ... but ONE with at most this many fits in flight: more, shorter workgroups (latency regime)
 
 template <typename R>
 __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
                                                    const double* __restrict__ theta_all,
                                                    R* __restrict__ Kall, int64_t N,
                                                    int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
-                                                   int write_upper, uint64_t term_mask, double diag_override) {
+                                                   int tpw, int write_upper, uint64_t term_mask, double diag_override) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -451,8 +452,8 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
   stage_exp_table(tab, tid);
   TileCtx t{fi, fj, tab + (tid & 31), FC + (int64_t)b * max_fact * 4, tid >> 4, tid & 15};
   const double noise = diag_override >= 0.0 ? diag_override : th[sp->noise_param];
-  for (int tt = 0; tt < GRAM_TPW; ++tt) {
-    const int tile = blockIdx.x * GRAM_TPW + tt;
+  for (int tt = 0; tt < tpw; ++tt) {
+    const int tile = blockIdx.x * tpw + tt;
     if (tile >= ntiles) break;
     int ti, tj;
     tri_decode(tile, ti, tj);
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
                                                     const double* __restrict__ alpha_all,
                                                     double* __restrict__ part, int64_t N,
                                                     int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
-                                                    int nwg) {
+                                                    int tpw, int part_stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -596,8 +597,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
     if (quad_leader) __hip_atomic_fetch_add(&red[slot * 64 + quad], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
-  for (int tt = 0; tt < TRACE_TPW; ++tt) {
-    const int tile = blockIdx.x * TRACE_TPW + tt;
+  for (int tt = 0; tt < tpw; ++tt) {
+    const int tile = blockIdx.x * tpw + tt;
     if (tile >= ntiles) break;
     int ti, tj;
     tri_decode(tile, ti, tj);
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
   }
   if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[(nred - 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
-  double* out = part + ((int64_t)b * nwg + blockIdx.x) * np;
+  double* out = part + ((int64_t)b * part_stride + blockIdx.x) * np;
   for (int p = tid; p < np; p += 256) out[p] = pacc[p];
 }
 
@@ -681,14 +682,16 @@ static void launch_features(Problem& p, hipStream_t st, int slot0, int nb) {
 }
 
 static size_t gram_lds_bytes(const Problem& p) { return ((size_t)2 * p.max_feat * GT + EXPTAB_DOUBLES) * sizeof(double); }
-static int gram_nwg(const Problem& p) { return (p.ntiles() + GRAM_TPW - 1) / GRAM_TPW; }
+static int gram_tpw(int nb) { return nb <= FEW_FITS ? 1 : GRAM_TPW; }
 
 template <typename R>
 static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb, int write_upper, uint64_t term_mask,
                           double diag) {
-  dim3 grid(gram_nwg(p), nb), blk(256);
+  const int tpw = gram_tpw(nb);
+  dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
   hipLaunchKernelGGL(gram_kernel<R>, grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,
-                     p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), write_upper, term_mask, diag);
+                     p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask,
+                     diag);
 }
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
@@ -706,16 +709,22 @@ void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper)
   p.timer.work(ST_GRAM, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
 
-int trace_nwg(const Problem& p) { return (p.ntiles() + TRACE_TPW - 1) / TRACE_TPW; }
+// Workgroups per fit of the trace pass over nb fits (= partial-sum records per fit that the reduce pass adds up); a
+// fit's records start at slot * trace_part_stride(p) whatever nb is, so groups of different size never overlap.
+int trace_nwg(const Problem& p, int nb) {
+  const int tpw = nb <= FEW_FITS ? 1 : TRACE_TPW;
+  return (p.ntiles() + tpw - 1) / tpw;
+}
+int trace_part_stride(const Problem& p) { return p.ntiles(); }
 
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
-  int nwg = trace_nwg(p);
-  dim3 grid(nwg, nb), blk(256);
+  const int tpw = nb <= FEW_FITS ? 1 : TRACE_TPW;
+  dim3 grid(trace_nwg(p, nb), nb), blk(256);
   size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
 #define WV_TRACE_LAUNCH(RT, MU, KBUF)                                                                              \
   hipLaunchKernelGGL((trace_kernel<RT, MU>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
-                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), nwg)
+                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p))
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.f32) {
