@@ -134,6 +134,18 @@ void wv_lbfgs_default_opts(wv_lbfgs_opts* opts);
  * vector (trainable parameters in table order, the order
  * gpflow `trainable_variables` would be flattened in is irrelevant to L-BFGS). */
 int32_t wv_spec_check(const wv_kernel_spec* spec, int32_t* n_trainable_out);
+/* Block structure of longitudinal designs (the structures come from
+ * waveome/regularization.py:103-149: unit x numeric and categorical x numeric terms).
+ * column_out: the column c such that every additive term that is not identically zero
+ * carries a Categorical factor on c, or -1.  For such a structure K_y vanishes outside
+ * the blocks of equal labels of column c, and so do its Cholesky factor, the factor's
+ * inverse and K_y^-1: the device products then only walk the k inside the blocks
+ * (rows sorted by c give the saving; any order gives the same numbers). */
+int32_t wv_spec_block_column(const wv_kernel_spec* spec, int32_t* column_out);
+/* spans_out[2 g], spans_out[2 g + 1] for each 64-row granule g of ceil(N / 64) * 64 rows:
+ * the half-open row range that can share a label of `column` with a row of the granule,
+ * rounded outwards to multiples of 16 (what wv_problem_create uploads for such a structure). */
+int32_t wv_block_spans(const double* X, int64_t N, int32_t D, int32_t column, int32_t* spans_out);
 /* unconstrained trainables -> constrained full table (frozen entries = init). */
 int32_t wv_spec_constrain(const wv_kernel_spec* spec, const double* u, double* theta_out);
 /* constrained full table -> unconstrained trainables. */

@@ -1,0 +1,220 @@
+"""Block structure of longitudinal designs (structures of waveome/regularization.py:103-149).
+
+CPU: which structures qualify (`wv_spec_block_column`) and the span tables (`wv_block_spans`).
+GPU (`-m gpu`): the zero-block-skipping products give the SAME BITS as the dense path, and the oracle's numbers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from waveome_amd import ModelSpec, _lib
+from waveome_amd import kernels as K
+
+
+def _spec(kern, D=4):
+    return ModelSpec(kern, D, K.GaussianLikelihood(), K.ConstantMean())
+
+
+def _cat(d):
+    k = K.Categorical(active_dims=[d])
+    return k
+
+
+def test_block_column_of_structures():
+    unit, other = 3, 2
+    se = lambda d: K.SquaredExponential(active_dims=[d])
+    # every term carries Categorical[unit]: unit main effect + unit x numeric interactions
+    k = K.Sum([_cat(unit), K.Product([_cat(unit), se(0)]), K.Product([_cat(unit), K.Lin(active_dims=[1])])])
+    assert _spec(k).block_column() == unit
+    # a dense main effect breaks it; so does a different categorical
+    assert _spec(K.Sum([_cat(unit), se(0)])).block_column() == -1
+    assert _spec(K.Sum([_cat(unit), K.Product([_cat(other), se(0)])])).block_column() == -1
+    # terms with both categoricals: the lowest common column is reported
+    both = K.Sum([K.Product([_cat(unit), _cat(other), se(0)]), K.Product([_cat(other), _cat(unit)])])
+    assert _spec(both).block_column() == other
+    # a term that is identically zero (Empty factor) does not count
+    assert _spec(K.Sum([K.Product([_cat(unit), se(0)]), K.Empty()])).block_column() == unit
+    # a lone product, as the kernel search proposes them
+    assert _spec(K.Product([_cat(unit), K.Matern32(active_dims=[1])])).block_column() == unit
+    assert _spec(se(0)).block_column() == -1
+
+
+def _spans(X, col):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N, D = X.shape
+    out = np.zeros(2 * ((N + 63) // 64), dtype=np.int32)
+    _lib.check(_lib.load().wv_block_spans(_lib.as_dp(X), N, D, col, out.ctypes.data_as(C.POINTER(C.c_int32))),
+               "wv_block_spans")
+    return out.reshape(-1, 2)
+
+
+def test_block_spans_sorted_unsorted_and_padding():
+    # 5 units of 50 rows, sorted: granule g = rows 64 g .. 64 g + 63
+    N = 250
+    X = np.zeros((N, 2))
+    X[:, 1] = np.repeat(np.arange(5), 50)
+    sp = _spans(X, 1)
+    assert sp.shape == (4, 2)
+    # granule 0 holds units 0 (rows 0-49) and 1 (50-99) -> [0, 100) -> rounded outwards to 16: [0, 112)
+    assert tuple(sp[0]) == (0, 112)
+    # granule 1 = rows 64..127: units 1 (50-99) and 2 (100-149) -> [50, 150) -> [48, 160)
+    assert tuple(sp[1]) == (48, 160)
+    # last granule = rows 192..255: unit 3 (150-199), unit 4 (200-249), then 6 padding rows (each its own block)
+    assert tuple(sp[3]) == (144, 256)
+    # every row's range contains the row itself and all rows of its label
+    for i in range(N):
+        lab = np.flatnonzero(X[:, 1] == X[i, 1])
+        assert sp[i // 64, 0] <= lab.min() and lab.max() < sp[i // 64, 1]
+    # scattered labels: wide ranges, still covering
+    rng = np.random.default_rng(0)
+    Xs = X[rng.permutation(N)]
+    sps = _spans(Xs, 1)
+    for i in range(N):
+        lab = np.flatnonzero(Xs[:, 1] == Xs[i, 1])
+        assert sps[i // 64, 0] <= lab.min() and lab.max() < sps[i // 64, 1]
+    assert (sps[:, 1] - sps[:, 0]).min() > 150
+    # labels are compared after rint, like the Categorical kernel (kernels.py:19-32): 0.9 and 1.1 are one label
+    Xr = X.copy()
+    Xr[:, 1] += np.where(np.arange(N) % 2, 0.1, -0.1)
+    assert np.array_equal(_spans(Xr, 1), sp)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _longitudinal(seed, units, per_unit, sort=True):
+    rng = np.random.default_rng(seed)
+    N = units * per_unit
+    uid = np.repeat(np.arange(units), per_unit).astype(float)
+    t = np.tile(np.linspace(-1.5, 1.5, per_unit), units) + 0.05 * rng.normal(size=N)
+    z = rng.normal(size=N)
+    X = np.column_stack([t, z, uid])
+    Y = np.stack([np.sin(2 * t + 0.3 * uid) + 0.3 * z + 0.1 * uid + 0.1 * rng.normal(size=N) for _ in range(3)], axis=1)
+    if not sort:
+        perm = rng.permutation(N)
+        X, Y = X[perm], Y[perm]
+    return X, Y
+
+
+def _block_kernel():
+    u = lambda: K.Categorical(active_dims=[2])
+    return K.Sum([u(), K.Product([u(), K.SquaredExponential(active_dims=[0])]),
+                  K.Product([u(), K.Lin(active_dims=[1])]),
+                  K.Product([u(), K.Periodic(K.SquaredExponential(active_dims=[0]))])])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sort", [True, False])
+@pytest.mark.parametrize("units,per_unit", [(12, 40), (7, 150)])
+def test_block_skipping_is_bit_identical_to_dense_and_matches_oracle(units, per_unit, sort):
+    from oracle import gp_oracle as o
+    from waveome_amd.engine import Context, Problem
+
+    X, Y = _longitudinal(3, units, per_unit, sort)
+    spec = ModelSpec(_block_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
+    assert spec.block_column() == 2
+    rng = np.random.default_rng(1)
+    B = 3
+    U = spec.unconstrain()[None, :] + 0.3 * rng.normal(size=(B, spec.n_trainable))
+    cols = np.arange(B, dtype=np.int32) % Y.shape[1]
+    ctx = Context(0)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WV_BLOCKS"] = mode
+        try:
+            p = Problem(ctx, X, Y, spec, max_batch=B)
+        finally:
+            os.environ.pop("WV_BLOCKS", None)
+        f, g, st = p.value_grad(cols, U)
+        lml, _ = p.lml(cols, np.stack([spec.constrain(u) for u in U]))
+        Minv = p.dbg_stage(0, spec.constrain(U[0]), 1)
+        Kinv = p.dbg_stage(0, spec.constrain(U[0]), 2)
+        out[mode] = (f, g, lml, Minv, Kinv)
+        assert np.all(st == 0)
+        p.close()
+    ctx.close()
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(a, b)  # skipping exact zeros changes no bit
+    d = spec.to_dict()
+    for b in range(B):
+        fo, go = o.objective(d, U[b], X, Y[:, cols[b]])
+        assert abs(out["1"][0][b] - fo) <= 1e-10 * max(1.0, abs(fo))
+        assert np.max(np.abs(out["1"][1][b] - go)) <= 1e-7 * max(1.0, np.max(np.abs(go)))
+
+
+@pytest.mark.gpu
+def test_block_and_dense_structures_share_a_batch():
+    """A multi-structure work queue mixes block-diagonal and dense candidates in one launch (as the kernel search
+    does): every slot follows its own structure's table."""
+    from waveome_amd.engine import Context, Problem, lbfgs_opts
+
+    X, Y = _longitudinal(5, 10, 60)
+    u = lambda: K.Categorical(active_dims=[2])
+    kerns = [K.Product([u(), K.SquaredExponential(active_dims=[0])]),            # block diagonal
+             K.Sum([K.SquaredExponential(active_dims=[0]), u()]),                   # dense
+             K.Sum([u(), K.Product([u(), K.Matern32(active_dims=[1])])])]          # block diagonal
+    specs = [ModelSpec(k, 3, K.GaussianLikelihood(), K.ConstantMean()) for k in kerns]
+    assert [s.block_column() for s in specs] == [2, -1, 2]
+    ctx = Context(0)
+    opts = lbfgs_opts(maxiter=25)
+    tasks_spec = np.array([0, 1, 2, 0, 1, 2], dtype=np.int32)
+    tasks_col = np.array([0, 0, 0, 1, 1, 1], dtype=np.int32)
+    width = max(s.n_trainable for s in specs)
+    U0 = np.zeros((6, width))
+    for t, si in enumerate(tasks_spec):
+        U0[t, :specs[si].n_trainable] = specs[si].unconstrain()
+    pm = Problem(ctx, X, Y, specs, max_batch=6)
+    rm = pm.fit_multi(tasks_col, tasks_spec, U0, opts)
+    pm.close()
+    for t, si in enumerate(tasks_spec):
+        p1 = Problem(ctx, X, Y, specs[si], max_batch=1)
+        r1 = p1.fit(tasks_col[t:t + 1], U0[t:t + 1, :specs[si].n_trainable], opts)
+        p1.close()
+        np.testing.assert_array_equal(rm["loss"][t], r1["loss"][0])
+        np.testing.assert_array_equal(rm["u"][t, :specs[si].n_trainable], r1["u"][0])
+    ctx.close()
+
+
+def test_shared_inputs_sorted_by_keeps_rows_together():
+    from waveome_amd.parallel import SharedInputs
+
+    rng = np.random.default_rng(4)
+    X = np.column_stack([rng.normal(size=40), rng.integers(0, 5, 40).astype(float)])
+    Y = rng.normal(size=(40, 2))
+    sh = SharedInputs(X, Y)
+    assert sh.sorted_by(None) is sh
+    so = sh.sorted_by(1)
+    assert np.all(np.diff(so.X[:, 1]) >= 0)
+    # the same (x, y) pairs, units in their original relative order (stable)
+    key = lambda A, B: sorted(map(tuple, np.column_stack([A, B]).round(12)))
+    assert key(so.X, so.Y) == key(X, Y)
+    for u in range(5):
+        np.testing.assert_array_equal(so.X[so.X[:, 1] == u, 0], X[X[:, 1] == u, 0])
+    assert so.sorted_by(1) is so  # already sorted: nothing to do
+
+
+@pytest.mark.gpu
+def test_kernel_sweep_on_shuffled_longitudinal_data():
+    """GPSearch sorts the DEVICE copy of the data by the unit column (block structures gain, nothing else changes):
+    a sweep over shuffled rows gives the fits of the sorted rows, and the models keep the caller's row order."""
+    import pandas as pd
+
+    from waveome_amd.engine import Context
+    from waveome_amd.model_search import GPSearch
+
+    X, Y = _longitudinal(8, 9, 30, sort=True)
+    perm = np.random.default_rng(2).permutation(len(X))
+    u = lambda: K.Categorical(active_dims=[0])
+    structures = {"unit x se": K.Sum([u(), K.Product([u(), K.SquaredExponential(active_dims=[1])])]),
+                  "dense": K.Sum([u(), K.SquaredExponential(active_dims=[1])])}
+    ctx = Context(0)
+    tables = []
+    for rows in (np.arange(len(X)), perm):
+        Xd = pd.DataFrame({"unit": X[rows, 2], "t": X[rows, 0], "z": X[rows, 1]})
+        Yd = pd.DataFrame({f"y{p}": Y[rows, p] for p in range(2)})
+        gps = GPSearch(Xd, Yd, unit_col="unit")
+        tables.append(gps.kernel_sweep(structures, context=ctx))
+        m = gps.sweep_models[("y0", "unit x se")]
+        np.testing.assert_array_equal(np.asarray(m.data[0])[:, 0], gps.X["unit"].to_numpy())  # caller's order
+    a, b = tables
+    np.testing.assert_allclose(a["loss"].to_numpy(), b["loss"].to_numpy(), rtol=1e-7, atol=1e-7)
+    ctx.close()

@@ -63,6 +63,8 @@ SIGNATURES = {
     "wv_last_error": (C.c_char_p, []),
     "wv_lbfgs_default_opts": (None, [C.POINTER(LbfgsOpts)]),
     "wv_spec_check": (C.c_int32, [C.POINTER(KernelSpec), _ip]),
+    "wv_spec_block_column": (C.c_int32, [C.POINTER(KernelSpec), _ip]),
+    "wv_block_spans": (C.c_int32, [_dp, C.c_int64, C.c_int32, C.c_int32, _ip]),
     "wv_spec_constrain": (C.c_int32, [C.POINTER(KernelSpec), _dp, _dp]),
     "wv_spec_unconstrain": (C.c_int32, [C.POINTER(KernelSpec), _dp, _dp]),
     "wv_spec_log_prior": (C.c_int32, [C.POINTER(KernelSpec), _dp, _dp, _dp]),

@@ -293,7 +293,8 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_spec) hipHostFree(g.h_spec);
   }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
-                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.Kbuf32, p.Mbuf32, p.MTbuf32,
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.dspans, p.dspec_span, p.Kbuf32, p.Mbuf32,
+                  p.MTbuf32,
                   p.Pbuf32};
   for (void* q : ptrs)
     if (q) hipFree(q);
@@ -301,6 +302,27 @@ void wv_problem_destroy(wv_problem* h) {
 }
 
 int64_t wv_problem_workspace_bytes(const wv_problem* h) { return h ? h->p.workspace_bytes : 0; }
+
+// Block structure of structure `si`: if every non-zero term carries a Categorical factor on one column,
+// point the structure at that column's span table (built from the host copy of X on first use).  WV_BLOCKS=0 at
+// problem creation keeps everything dense (the two paths give bit-identical results: tests/test_gpu_blocks.py).
+static int register_block_structure(Problem& p, int si) {
+  int32_t table = -1;
+  const int col = p.hX.empty() ? -1 : block_column(p.specs[si]);
+  if (col >= 0) {
+    if (p.span_table_of_col[col] < 0) {
+      std::vector<int32_t> sp;
+      block_spans(p.hX.data(), p.N, p.D, col, p.Npad, sp);
+      WV_HIP_TRY(hipMemcpy(p.dspans + (int64_t)p.n_span_tables * sp.size(), sp.data(), sizeof(int32_t) * sp.size(),
+                           hipMemcpyHostToDevice));
+      p.span_table_of_col[col] = p.n_span_tables++;
+    }
+    table = p.span_table_of_col[col];
+  }
+  // (a new entry is referenced by no slot yet, so kernels in flight do not read it)
+  WV_HIP_TRY(hipMemcpy(p.dspec_span + si, &table, sizeof(int32_t), hipMemcpyHostToDevice));
+  return WV_OK;
+}
 
 int32_t wv_problem_create(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y,
                           int32_t P, const wv_kernel_spec* spec, int32_t max_batch,
@@ -395,6 +417,8 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
   bool ok = alloc((void**)&p.dX, sizeof(double) * Np * D) && alloc((void**)&p.dY, sizeof(double) * Np * P) &&
             alloc((void**)&p.dspec, sizeof(DevSpec) * p.spec_cap) &&
             alloc((void**)&p.dslotspec, sizeof(int32_t) * max_batch) &&
+            alloc((void**)&p.dspans, sizeof(int32_t) * 2 * (Np / 64) * D) &&
+            alloc((void**)&p.dspec_span, sizeof(int32_t) * p.spec_cap) &&
             (p.f32 ? alloc((void**)&p.Kbuf32, sizeof(float) * mat * max_batch) &&
                          alloc((void**)&p.Mbuf32, sizeof(float) * mat * max_batch) &&
                          alloc((void**)&p.MTbuf32, sizeof(float) * mat * max_batch) &&
@@ -439,6 +463,19 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
                          y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemcpy(p.dspec, hspecs.data(), sizeof(DevSpec) * n_specs, hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemset(p.dslotspec, 0, sizeof(int32_t) * max_batch));
+  WV_HIP_TRY(hipMemset(p.dspec_span, 0xff, sizeof(int32_t) * p.spec_cap));  // -1: dense
+  {
+    const char* e = std::getenv("WV_BLOCKS");
+    if (!(e && std::atoi(e) == 0) && !p.f32) {  // (the float32 GEMM does not read the tables)
+      p.hX.resize((size_t)N * D);
+      WV_HIP_TRY(hipMemcpy(p.hX.data(), X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+      p.span_table_of_col.assign(D, -1);
+      for (int si = 0; si < n_specs; ++si) {
+        const int rc = register_block_structure(p, si);
+        if (rc != WV_OK) return rc;
+      }
+    }
+  }
   // batch groups: independent streams, each advancing its own set of fits.  Measured on MI355X
   // (N = 2048, 1024 tasks): ONE group of 256 slots gives 3720 evaluations/s, two groups of 128 give
   // 3500 - large launches amortise the serial small kernels better than cross-stream overlap does -
@@ -1159,7 +1196,7 @@ int32_t wv_problem_add_spec(wv_problem* h, const wv_kernel_spec* spec, int32_t* 
   WV_HIP_TRY(hipMemcpy(p.dspec + p.specs.size(), &d, sizeof(DevSpec), hipMemcpyHostToDevice));
   *index_out = (int32_t)p.specs.size();
   p.specs.push_back(std::move(sp));
-  return WV_OK;
+  return register_block_structure(p, *index_out);
 }
 
 struct wv_queue {

@@ -879,6 +879,17 @@ static GemmArgsT<R> base_args(const Problem& p, int slot0, int nb) {
   (void)slot0;
   return a;
 }
+// Block structure: (r0, c0, k0) = the K_y index of the product's row 0, column 0 and k = 0 (see GemmArgsT::spans)
+template <typename R>
+static void with_spans(GemmArgsT<R>& a, const Problem& p, int slot0, int64_t r0, int64_t c0, int64_t k0) {
+  if (p.n_span_tables == 0) return;
+  a.spans = p.dspans;
+  a.spec_span = p.dspec_span;
+  a.slot_spec = p.dslotspec;
+  a.span_nblk = (int)(p.Npad / 64);
+  a.slot0 = slot0;
+  a.sp_r0 = (int)r0; a.sp_c0 = (int)c0; a.sp_k0 = (int)k0;
+}
 
 void cholesky(Problem& p, hipStream_t st, int slot0, int nb) {
   const int64_t Np = p.Npad, mat = Np * Np;
@@ -1017,6 +1028,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.C = nullptr;
     a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
+    with_spans(a, p, slot0, o + h1, o, o);
     p.timer.begin(st, ST_CHOL_TRSM);
     launch_gemm(st, a, true, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
@@ -1028,6 +1040,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   su.C = K0 + (o + h1) * Np + (o + h1);
   su.M = (int)h2; su.N = (int)h2; su.kb = 0; su.ke = (int)h1;
   su.alpha = -1.0; su.beta = 1.0; su.tri = 1; su.tag = 2;
+  with_spans(su, p, slot0, o + h1, o + h1, o);
   // T = S * M11 over the dead A21 block;  A(m, k) = S'[k][m],  B(n, k) = M11[k][n].  Off the critical path: only
   // M21, after the whole right child, reads it.
   GemmArgsT<R> tp = base_args<R>(p, slot0, nb);
@@ -1035,6 +1048,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   tp.B = M0 + o * Np + o;
   tp.C = K0 + (o + h1) * Np + o;
   tp.M = (int)h2; tp.N = (int)h1; tp.kb = 0; tp.ke = (int)h1; tp.klo_mode = 2;
+  with_spans(tp, p, slot0, o + h1, o, o);
   const int tile_su = pick_bn(h2, h2, nb, true), tile_tp = pick_bn(h2, h1, nb, false);
   bool paired = false;
   if constexpr (std::is_same<R, double>::value) {
@@ -1065,6 +1079,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.C = M0 + (o + h1) * Np + o;
     a.CT = MT0 + o * Np + (o + h1); a.sCT = mat; a.ldct = (int)Np; a.tout = 2;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h2; a.khi_mode = 1; a.alpha = -1.0;
+    with_spans(a, p, slot0, o + h1, o, o + h1);
     p.timer.begin(st, ST_TRTRI_B);
     launch_gemm(st, a, false, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
@@ -1121,6 +1136,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.C = nullptr;
     a.CT = S0; a.sCT = sS; a.ldct = (int)h2; a.tout = 1;
     a.M = (int)h2; a.N = (int)h1; a.kb = 0; a.ke = (int)h1; a.khi_mode = 2;
+    with_spans(a, p, slot0, o + h1, o, o);
     p.timer.begin(st, ST_CHOL_TRSM);
     launch_gemm(st, a, true, false, pick_bn(h2, h1, nb, false));
     p.timer.end(st);
@@ -1136,6 +1152,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     a.C = K0 + (o + h1) * Np + (o + h1);
     a.M = (int)h2; a.N = (int)h2; a.kb = 0; a.ke = (int)h1;
     a.alpha = -1.0; a.beta = 1.0; a.tri = 1;
+    with_spans(a, p, slot0, o + h1, o + h1, o);
     p.timer.begin(st, ST_CHOL_TRAIL);
     launch_gemm(st, a, false, false, pick_bn(h2, h2, nb, true));
     p.timer.end(st);
@@ -1164,6 +1181,7 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   a.C = mb.K + (int64_t)slot0 * mat;
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
+  with_spans(a, p, slot0, 0, 0, 0);
   p.timer.begin(st, ST_LAUUM);
   // 128-wide tiles (its own kernel symbols: off-diagonal + diagonal-tile launch) unless so few fits are in flight
   // that the two dependent launches and their few long tiles are the cost: then 64-wide tiles, one launch

@@ -87,6 +87,13 @@ struct GemmArgsT {
   int32_t latin;
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
   int32_t prio;        // timing-experiment switches (WV_GEMM_DBG; 0 in production)
+  // Block structure (wv_spec.hpp, block_column): when `spans` is set, a matrix whose structure (slot_spec -> spec_span)
+  // has a span table only walks the k that can meet a non-zero in both operands: with (sp_r0, sp_c0, sp_k0) the
+  // K_y-index of the product's row 0, column 0 and k = 0, a tile's range is cut to span(rows) ^ span(columns).
+  const int32_t* spans;      // [tables][span_nblk][2]
+  const int32_t* spec_span;  // [specs]  table index or -1
+  const int32_t* slot_spec;  // [slots]
+  int32_t span_nblk, slot0, sp_r0, sp_c0, sp_k0;
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;  // float32 storage path (wv_gemm32.hip)
@@ -144,6 +151,13 @@ struct Problem {
   // stride np_stride = max n_params (each DevSpec's n_params field holds that stride; the unused tail of
   // a slot's parameter row / gradient record is zero).
   std::vector<Spec> specs;
+  // block structure: one span table per column of X that some structure is block diagonal in (built on demand from
+  // the host copy of X), and per structure the index of its table (-1: dense)
+  std::vector<double> hX;             // [N][D]
+  std::vector<int> span_table_of_col; // [D] table index or -1
+  int n_span_tables = 0;
+  int32_t* dspans = nullptr;          // [D][Npad / 64][2]
+  int32_t* dspec_span = nullptr;      // [spec_cap]
   int np_stride = 0, max_feat = 0;
   int32_t* dslotspec = nullptr;  // [max_batch]
   int64_t N = 0, Npad = 0;

@@ -192,6 +192,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   if (g.klo_mode == 2) kb = max(kb, n0 + g.koff);
   if (g.khi_mode == 1) ke = min(ke, m0 + BM + g.koff);
   if (g.khi_mode == 2) ke = min(ke, n0 + BN + g.koff);
+  // Block structure: only the k that can meet a non-zero of both operands (GemmArgsT::spans; tables hold multiples
+  // of 16, origins are multiples of 64).  An empty range leaves the epilogue: zeros for beta = 0, nothing for beta = 1.
+  const int32_t* span_tab = nullptr;
+  if (g.spans) {
+    const int t = g.spec_span[g.slot_spec[g.slot0 + b]];
+    if (t >= 0) {
+      span_tab = g.spans + (int64_t)t * g.span_nblk * 2;
+      int lo_r = 1 << 30, hi_r = 0, lo_c = 1 << 30, hi_c = 0;
+      const int gr0 = (g.sp_r0 + m0) >> 6, gr1 = (g.sp_r0 + min(m0 + BM, g.M) - 1) >> 6;
+      const int gc0 = (g.sp_c0 + n0) >> 6, gc1 = (g.sp_c0 + min(n0 + BN, g.N) - 1) >> 6;
+      for (int q = gr0; q <= gr1; ++q) { lo_r = min(lo_r, span_tab[2 * q]); hi_r = max(hi_r, span_tab[2 * q + 1]); }
+      for (int q = gc0; q <= gc1; ++q) { lo_c = min(lo_c, span_tab[2 * q]); hi_c = max(hi_c, span_tab[2 * q + 1]); }
+      kb = max(kb, max(lo_r, lo_c) - g.sp_k0);
+      ke = max(kb, min(ke, min(hi_r, hi_c) - g.sp_k0));
+      if (ke == kb && g.beta == 1.0 && TOUT == 0) return;  // C += 0
+    }
+  }
 
   const double* __restrict__ A = g.A + (int64_t)b * g.sA;
   const double* __restrict__ B = g.B + (int64_t)b * g.sB;
@@ -242,6 +259,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
     if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
     if (g.khi_mode == 2) wke = min(wke, wc + WCOLS + g.koff);
     if (g.tri && !TRIOPT && wc + g.tri_off > wr + 63) wke = wkb;  // nothing to do
+    if (span_tab) {  // the wave's own 64 rows and (at most 64, granule-aligned) columns
+      const int qr = (g.sp_r0 + min(wr, g.M - 1)) >> 6, qc = (g.sp_c0 + min(wc, g.N - 1)) >> 6;
+      wkb = max(wkb, max(span_tab[2 * qr], span_tab[2 * qc]) - g.sp_k0);
+      wke = min(wke, min(span_tab[2 * qr + 1], span_tab[2 * qc + 1]) - g.sp_k0);
+    }
   }
   d2 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb) / KC;

@@ -1,7 +1,11 @@
 #include "wv_spec.hpp"
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
+#include <utility>
 
 #include "wv_lbfgs.hpp"
 
@@ -178,6 +182,62 @@ double Spec::log_prior(const double* theta, double* grad, double scale_override)
 // ---------------- C-ABI: host-only entry points ----------------
 using namespace wv;
 
+
+namespace wv {
+int block_column(const Spec& s) {
+  uint32_t common = ~0u;
+  bool any = false;
+  for (int t = 0; t < s.n_terms(); ++t) {
+    uint32_t cats = 0;
+    bool zero = false;
+    for (int f = s.term_start[t]; f < s.term_start[t + 1]; ++f) {
+      if (s.factors[f].type == WV_K_EMPTY) zero = true;
+      if (s.factors[f].type == WV_K_CAT) cats |= s.factors[f].dim_mask;
+    }
+    if (zero) continue;  // the term contributes nothing
+    common &= cats;
+    any = true;
+  }
+  if (!any || common == 0) return -1;
+  return __builtin_ctz(common);
+}
+
+void block_spans(const double* X, int64_t N, int D, int col, int64_t Npad, std::vector<int32_t>& spans) {
+  // labels as the device compares them: rint(x); NaN never equals anything, so such a row pairs with itself only
+  std::unordered_map<long long, std::pair<int32_t, int32_t>> range;  // label -> first, last row
+  std::vector<long long> label(N);
+  std::vector<char> lone(N, 0);
+  for (int64_t i = 0; i < N; ++i) {
+    const double x = X[i * D + col];
+    if (!(std::fabs(x) < 9e15)) {
+      lone[i] = 1;
+      continue;
+    }
+    label[i] = std::llrint(x);
+    auto it = range.find(label[i]);
+    if (it == range.end()) range.emplace(label[i], std::make_pair((int32_t)i, (int32_t)i));
+    else it->second.second = (int32_t)i;
+  }
+  const int64_t ng = Npad / 64;
+  spans.assign(2 * ng, 0);
+  for (int64_t g = 0; g < ng; ++g) {
+    int32_t lo = INT32_MAX, hi = 0;
+    for (int64_t i = 64 * g; i < 64 * (g + 1); ++i) {
+      int32_t a = (int32_t)i, b = (int32_t)i;
+      if (i < N && !lone[i]) {
+        const auto& r = range[label[i]];
+        a = r.first;
+        b = r.second;
+      }
+      lo = std::min(lo, a);
+      hi = std::max(hi, b + 1);
+    }
+    spans[2 * g] = lo / 16 * 16;
+    spans[2 * g + 1] = (int32_t)std::min<int64_t>(Npad, (hi + 15) / 16 * 16);
+  }
+}
+}  // namespace wv
+
 extern "C" {
 
 int32_t wv_abi_version(void) { return WV_ABI_VERSION; }
@@ -191,6 +251,32 @@ void wv_lbfgs_default_opts(wv_lbfgs_opts* o) {
   o->maxls = 20;
   o->ftol = 2.220446049250313e-09;
   o->gtol = 1e-05;
+}
+
+int32_t wv_spec_block_column(const wv_kernel_spec* spec, int32_t* column_out) {
+  Spec s;
+  std::string e = Spec::parse(spec, s);
+  if (!e.empty()) {
+    set_error(e);
+    return WV_E_SPEC;
+  }
+  if (!column_out) {
+    set_error("null argument");
+    return WV_E_BADARG;
+  }
+  *column_out = block_column(s);
+  return WV_OK;
+}
+
+int32_t wv_block_spans(const double* X, int64_t N, int32_t D, int32_t column, int32_t* spans_out) {
+  if (!X || !spans_out || N < 1 || D < 1 || column < 0 || column >= D) {
+    set_error("wv_block_spans: bad argument");
+    return WV_E_BADARG;
+  }
+  std::vector<int32_t> sp;
+  block_spans(X, N, D, column, (N + 63) / 64 * 64, sp);
+  std::memcpy(spans_out, sp.data(), sizeof(int32_t) * sp.size());
+  return WV_OK;
 }
 
 int32_t wv_spec_check(const wv_kernel_spec* spec, int32_t* n_trainable_out) {

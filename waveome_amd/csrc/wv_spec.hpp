@@ -35,6 +35,17 @@ struct Spec {
   double log_prior(const double* theta, double* grad /*n_params or null*/, double scale_override = -1.0) const;
 };
 
+// ---- block structure (designs in which every additive term carries the same Categorical factor) ----
+// The column c such that every term that is not identically zero has a Categorical factor on column c, or -1.  Then
+// K_y[i][j] = 0 whenever rint(x_ic) != rint(x_jc): K_y, its Cholesky factor, the factor's inverse and K_y^-1 are all
+// zero outside the blocks of equal labels, and the O(N^3) products only need the k inside them (wv_gemm.hip).
+int block_column(const Spec& s);
+// spans[2 g], spans[2 g + 1]: for the 64-row granule g of the padded index range, the half-open range [lo, hi) of row
+// indices that can share a label of column `col` with any row of the granule (first to last occurrence of each of its
+// labels), rounded outwards to multiples of 16; padding rows (identity rows of K_y) only pair with themselves.  Rows
+// sorted by the column give tight ranges, scattered labels wide ones - correct either way.
+void block_spans(const double* X, int64_t N, int D, int col, int64_t Npad, std::vector<int32_t>& spans);
+
 int n_factor_params(int type);
 double softplus(double u);
 double inv_softplus(double x);

@@ -46,6 +46,15 @@ class GPSearch:
             self._standardize_continuous()
         self._transform_outputs(Y_transform)
 
+    def _block_sort_column(self):
+        """Column the device-side copies of the data are sorted by (rows of a unit / category contiguous): candidate
+        structures in which every term carries that column's Categorical factor are block diagonal, and the device
+        products then skip the zero blocks.  The unit column if there is one, else the first
+        categorical column, else None."""
+        if self.unit_idx is not None:
+            return self.unit_idx
+        return self.cat_idx[0] if self.cat_idx else None
+
     @staticmethod
     def _encode_categoricals(X, cat_names):
         """Text-like categorical columns become float codes in order of first appearance (pd.factorize); the
@@ -274,7 +283,8 @@ class GPSearch:
         if mean_function is None:
             mean_function = K.ConstantMean()
         shared = parallel.broadcast_inputs(self.X.to_numpy(dtype=np.float64), self.Y.to_numpy(dtype=np.float64))
-        Xn, Yn = shared.X, shared.Y
+        Xn, Yn = shared.X, shared.Y  # (host-side models keep the caller's row order)
+        shared = shared.sorted_by(self._block_sort_column())  # the device fits do not care, block structures gain
         N, P, S = Xn.shape[0], Yn.shape[1], len(names)
         ctx = context or default_context()
         opts = lbfgs_opts(maxiter=num_opt_iter)
@@ -372,7 +382,8 @@ class GPSearch:
         if random_seed is not None:
             np.random.seed(random_seed)
         shared = parallel.broadcast_inputs(self.X.to_numpy(dtype=np.float64), self.Y.to_numpy(dtype=np.float64))
-        Xn, Yn = shared.X, shared.Y
+        Xn, Yn = shared.X, shared.Y  # (host-side models keep the caller's row order)
+        shared = shared.sorted_by(self._block_sort_column())  # the device fits do not care, block structures gain
         P = Yn.shape[1]
         print(f"Building {len(self.out_names)} models...")
         start_time = time.time()

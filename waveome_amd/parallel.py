@@ -94,6 +94,26 @@ class SharedInputs:
     def __init__(self, X, Y, Xt=None, Yt=None):
         self.X, self.Y, self._Xt, self._Yt = X, Y, Xt, Yt
 
+    def sorted_by(self, col: Optional[int]) -> "SharedInputs":
+        """The same inputs with the rows stably sorted by the labels (rint) of column `col` - the inputs themselves
+        when they already are, or when col is None.  Fits do not depend on the row order (beyond rounding), but a
+        kernel structure in which every term carries Categorical[col] (unit x numeric interactions,
+        waveome/regularization.py:103-121; lone products in the kernel search) is block diagonal in these labels, and
+        with sorted rows the device products skip the zero blocks."""
+        if col is None:
+            return self
+        labels = np.rint(self.X[:, int(col)])
+        if np.all(np.diff(labels) >= 0):
+            return self
+        perm = np.argsort(labels, kind="stable")
+        Xt = Yt = None
+        if self._Xt is not None:
+            import torch
+
+            idx = torch.as_tensor(perm, device=self._Xt.device)
+            Xt, Yt = self._Xt[idx].contiguous(), self._Yt[:, idx].contiguous()
+        return SharedInputs(np.ascontiguousarray(self.X[perm]), np.ascontiguousarray(self.Y[perm]), Xt, Yt)
+
     def problem(self, ctx, spec, max_batch, capacity=None):
         """engine.Problem on these inputs: from the broadcast's device tensors when they live on ctx's GPU
         (device-to-device copy inside wv_problem_create), from the host copies otherwise."""

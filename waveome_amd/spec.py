@@ -187,6 +187,13 @@ class ModelSpec:
         return spec
 
     # ---- host helpers routed through the C-ABI (same code the device path uses) ----
+    def block_column(self) -> int:
+        """The column whose Categorical factor every non-zero additive term carries, or -1: for such
+        a structure K_y is block diagonal in the labels of that column and the device products skip the zero blocks."""
+        col = C.c_int32(-2)
+        _lib.check(_lib.load().wv_spec_block_column(C.byref(self.to_ctypes()), C.byref(col)), "wv_spec_block_column")
+        return int(col.value)
+
     def constrain(self, u) -> np.ndarray:
         lib = _lib.load()
         u = np.ascontiguousarray(u, dtype=np.float64)
