@@ -22,12 +22,6 @@ constexpr int OUTER = 256;  // outer Cholesky block
 // (16 rows x 2 k per half-wave -> 2 row + k) free of bank conflicts; the column-wise reads are 2-way
 constexpr int DS = NB + 2;
 
-// ---------------------------------------------------------------------------------------
-// potrf_diag: factor the 64x64 diagonal block at (j0, j0) of every slot's Kbuf in LDS, write
-// L_jj back (upper part zeroed), inv(L_jj) into Mbuf's diagonal block, sum log L_ii.
-// A non-positive / NaN pivot sets status[slot] = 1 and is replaced by 1 so the pipeline
-// keeps running on finite numbers (the host reports +inf for that task).
-// ---------------------------------------------------------------------------------------
 // 4 consecutive elements in their own type
 __device__ inline void ld4(const double* __restrict__ p, double (&v)[4]) { load4(p, v); }
 __device__ inline void st4(double* __restrict__ p, const double (&v)[4]) { store4(p, v); }
@@ -68,122 +62,10 @@ __device__ inline void inv_level(const R* __restrict__ L, R* __restrict__ X, R* 
   __syncthreads();
 }
 
-// Register-tiled right-looking Cholesky of the 64x64 block: thread (ty, tx) of a 16 x 16 grid owns
-// rows 4 ty.., columns 4 tx.. in registers; per column one LDS broadcast of the pivot column and
-// ONE barrier (the column buffer is double-buffered).
 template <typename R>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(R* __restrict__ Kall, R* __restrict__ Mall,
-                                                         R* __restrict__ MTall,
-                                                         double* __restrict__ logdet,
-                                                         int32_t* __restrict__ status,
-                                                         int64_t Npad, int nblk, int slot0, int j0) {
-  __shared__ R L[NB * DS];
-  __shared__ R X[NB * DS];
-  __shared__ R T[INV_SCRATCH];
-  __shared__ R colbuf[2][NB];
-  __shared__ int bad;
-  const int b = slot0 + blockIdx.x;
-  R* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
-  R* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  if (tid == 0) bad = 0;
-  R a[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ld4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, a[r]);
-  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
-  bool anybad = false;
-  for (int jb = 0; jb < 16; ++jb) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = 4 * jb + jj;
-      R* cb = colbuf[j & 1];
-      if (tx == jb && ty >= jb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cb[4 * ty + r] = a[r][jj];
-      }
-      __syncthreads();
-      R piv = cb[j];
-      const bool ok = piv > R(0);  // false for NaN as well
-      if (!ok) { piv = 1; anybad = true; }
-      const R inv = rsq(piv);
-      if (ty >= tx && tx >= jb) {
-        R lr[4], lc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lr[r] = cb[4 * ty + r] * inv;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) lc[c] = cb[4 * tx + c] * inv;
-        if (tx == jb) {
-          // finalise column j (rows > j; the diagonal becomes piv * inv = sqrt(piv))
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r][jj] = (ty == jb && r == jj) ? piv * inv : lr[r];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (c > jj) a[r][c] -= lr[r] * lc[c];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) a[r][c] -= lr[r] * lc[c];
-        }
-      }
-    }
-  }
-  // L to LDS (upper part zeroed) and back to HBM
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = 4 * ty + r, jc = 4 * tx + c;
-      const R v = (jc <= i) ? a[r][c] : R(0);
-      a[r][c] = v;
-      L[i * DS + jc] = v;
-    }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) st4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, a[r]);
-  if (anybad && tid == 0) bad = 1;
-  __syncthreads();
-  if (tid < 64) {
-    double v = log((double)L[tid * DS + tid]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (tid == 0) {
-      logdet[(int64_t)b * nblk + j0 / NB] = v;
-      if (bad) status[b] = 1;
-    }
-  }
-  // ---- inverse of the lower-triangular block by recursive doubling ----
-  if (tid < 64) {  // level 0: sixteen 4x4 diagonal blocks, one thread per column (a short dependent chain)
-    const int blk = tid >> 2, c = tid & 3, o = blk * 4;
-    X[(o + c) * DS + o + c] = R(1) / L[(o + c) * DS + o + c];
-    for (int i = c + 1; i < 4; ++i) {
-      R s = 0;
-      for (int k = c; k < i; ++k) s += L[(o + i) * DS + o + k] * X[(o + k) * DS + o + c];
-      X[(o + i) * DS + o + c] = -s / L[(o + i) * DS + o + i];
-    }
-  }
-  __syncthreads();
-  inv_level<4>(L, X, T, tid);
-  inv_level<8>(L, X, T, tid);
-  inv_level<16>(L, X, T, tid);
-  inv_level<32>(L, X, T, tid);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * ty + r;
-    const R v[4] = {X[i * DS + 4 * tx], X[i * DS + 4 * tx + 1], X[i * DS + 4 * tx + 2], X[i * DS + 4 * tx + 3]};
-    st4(M + (int64_t)i * Npad + 4 * tx, v);
-  }
-  if (MTall) {  // transposed image of the inverse block
-    R* MT = MTall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * ty + r;
-      const R v[4] = {X[(4 * tx) * DS + i], X[(4 * tx + 1) * DS + i], X[(4 * tx + 2) * DS + i], X[(4 * tx + 3) * DS + i]};
-      st4(MT + (int64_t)i * Npad + 4 * tx, v);
-    }
-  }
-}
+__global__ void potrf_diag_kernel(R* __restrict__ Kall, R* __restrict__ Mall, R* __restrict__ MTall,
+                                  double* __restrict__ logdet, int32_t* __restrict__ status, int64_t Npad, int nblk,
+                                  int slot0, int j0);  // (defined below, after the helpers it shares with potrf128)
 
 void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
   p.timer.begin(st, ST_POTRF_DIAG);
@@ -403,6 +285,82 @@ __device__ inline void invert64(const R* __restrict__ L, R* __restrict__ X, R* _
   inv_level_mma<16>(L, X, T, tid);
   WV_STAMP(19);
   inv_level_mma<32>(L, X, T, tid);
+}
+
+// potrf_diag: the 64 x 64 leaf (block counts that are not a multiple of two leave one per odd node; also the
+// stand-alone right-looking schedule): factor the block at (j0, j0) of every slot's Kbuf, write L_jj back (upper part
+// zeroed), inv(L_jj) into Mbuf's diagonal block (and its transpose into MTbuf), sum log L_ii.  A non-positive / NaN
+// pivot sets status[slot] = 1 and is replaced by 1 so the pipeline keeps running on finite numbers (the host reports
+// +inf for that task).  Same machinery as potrf128 (blocked factor, MFMA inversion levels, float64 inside).
+template <typename R>
+__global__ __launch_bounds__(256, 2) void potrf_diag_kernel(R* __restrict__ Kall, R* __restrict__ Mall,
+                                                            R* __restrict__ MTall, double* __restrict__ logdet,
+                                                            int32_t* __restrict__ status, int64_t Npad, int nblk,
+                                                            int slot0, int j0) {
+  using W = double;
+  __shared__ W L[NB * DS];
+  __shared__ W X[NB * DS];
+  __shared__ W T[INV_SCRATCH];
+  __shared__ W pbuf[NB * 4];
+  __shared__ W dinfo[16 * DINFO];
+  __shared__ int bad;
+  const int b = slot0 + blockIdx.x;
+  R* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  R* M = Mall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  if (tid == 0) bad = 0;
+  W a[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    R v[4];
+    ld4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, v);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[r][c] = (W)v[c];
+  }
+  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
+  const bool anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
+  // L to LDS (upper part zeroed) and back to HBM
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    R v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 4 * ty + r, jc = 4 * tx + c;
+      const W l = (jc <= i) ? a[r][c] : W(0);
+      L[i * DS + jc] = l;
+      v[c] = (R)l;
+    }
+    st4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, v);
+  }
+  if (anybad) bad = 1;  // (same value from every writer)
+  diag_inverses<W>(dinfo, X, tid);
+  __syncthreads();
+  if (tid < 64) {
+    double v = log((double)L[tid * DS + tid]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (tid == 0) {
+      logdet[(int64_t)b * nblk + j0 / NB] = v;
+      if (bad) status[b] = 1;
+    }
+  }
+  invert64<W>(L, X, T, tid);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * ty + r;
+    const R v[4] = {(R)X[i * DS + 4 * tx], (R)X[i * DS + 4 * tx + 1], (R)X[i * DS + 4 * tx + 2], (R)X[i * DS + 4 * tx + 3]};
+    st4(M + (int64_t)i * Npad + 4 * tx, v);
+  }
+  if (MTall) {  // transposed image of the inverse block
+    R* MT = MTall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * ty + r;
+      const R v[4] = {(R)X[(4 * tx) * DS + i], (R)X[(4 * tx + 1) * DS + i], (R)X[(4 * tx + 2) * DS + i],
+                      (R)X[(4 * tx + 3) * DS + i]};
+      st4(MT + (int64_t)i * Npad + 4 * tx, v);
+    }
+  }
 }
 
 template <typename R>
