@@ -427,6 +427,18 @@ __device__ inline void tri_decode(int t, int& ti, int& tj) {
   tj = t - i * (i + 1) / 2;
 }
 
+// Block structure (wv_spec.hpp, block_spans): the span table of a slot's structure, or null; and "tile (ti, tj) of 64 x
+// 64 holds only structural zeros" = the rows that can share a label with tile row ti miss tile column tj entirely.
+__device__ inline const int32_t* block_span_table(const int32_t* __restrict__ spans, const int32_t* __restrict__ spec_span,
+                                                  int spec, int64_t Npad) {
+  if (!spans) return nullptr;
+  const int t = spec_span[spec];
+  return t < 0 ? nullptr : spans + (int64_t)t * (Npad / 64) * 2;
+}
+__device__ inline bool tile_is_zero(const int32_t* __restrict__ span, int ti, int tj) {
+  return span && ti != tj && (span[2 * ti] >= (tj + 1) * GT || span[2 * ti + 1] <= tj * GT);
+}
+
 constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup) ...
 constexpr int FEW_FITS = 8;  // ... but ONE with at most this many fits in flight: more, shorter workgroups (latency regime)
 
@@ -437,12 +449,15 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
                                                    const double* __restrict__ theta_all,
                                                    R* __restrict__ Kall, int64_t N,
                                                    int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
-                                                   int tpw, int write_upper, uint64_t term_mask, double diag_override) {
+                                                   int tpw, int write_upper, uint64_t term_mask, double diag_override,
+                                                   const int32_t* __restrict__ spans,
+                                                   const int32_t* __restrict__ spec_span) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const double* th = theta_all + (int64_t)b * sp->n_params;
   R* K = Kall + (int64_t)b * Npad * Npad;
+  const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
   const int tid = threadIdx.x;
   double* tab = smem;
   double* fi = smem + EXPTAB_DOUBLES;
@@ -457,12 +472,19 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
     if (tile >= ntiles) break;
     int ti, tj;
     tri_decode(tile, ti, tj);
-    __syncthreads();
-    stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
-    stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
-    __syncthreads();
     double sum[4][4];
-    kernel_sum_tile(sp, t, term_mask, sum);
+    if (tile_is_zero(span, ti, tj)) {  // block structure: no row of tile row ti shares a label with tile column tj
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sum[a][c] = 0.0;
+    } else {
+      __syncthreads();
+      stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
+      stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
+      __syncthreads();
+      kernel_sum_tile(sp, t, term_mask, sum);
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
@@ -571,7 +593,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
                                                     const double* __restrict__ alpha_all,
                                                     double* __restrict__ part, int64_t N,
                                                     int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
-                                                    int tpw, int part_stride) {
+                                                    int tpw, int part_stride, const int32_t* __restrict__ spans,
+                                                    const int32_t* __restrict__ spec_span) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -597,11 +620,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
     if (quad_leader) __hip_atomic_fetch_add(&red[slot * 64 + quad], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
+  const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
   for (int tt = 0; tt < tpw; ++tt) {
     const int tile = blockIdx.x * tpw + tt;
     if (tile >= ntiles) break;
     int ti, tj;
     tri_decode(tile, ti, tj);
+    if (tile_is_zero(span, ti, tj)) continue;  // dK/dtheta vanishes on the whole tile
     __syncthreads();
     stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
     stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
@@ -691,7 +716,7 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
   dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
   hipLaunchKernelGGL(gram_kernel<R>, grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask,
-                     diag);
+                     diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span);
 }
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
@@ -724,7 +749,8 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   p.timer.begin(st, ST_TRACE);
 #define WV_TRACE_LAUNCH(RT, MU, KBUF)                                                                              \
   hipLaunchKernelGGL((trace_kernel<RT, MU>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
-                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p))
+                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p), \
+                     p.n_span_tables ? p.dspans : nullptr, p.dspec_span)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.f32) {
