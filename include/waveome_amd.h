@@ -266,6 +266,11 @@ typedef struct {
   int32_t max_feat;    /* staged feature slots of one structure (<= 64) */
   int32_t max_factors; /* kernel factors of one structure (<= 128) */
   int32_t max_red;     /* gradient sums of one structure: 1-3 per trainable factor, + 1 */
+  int32_t nan_is_missing; /* != 0: a NaN in column p of Y marks that row as missing FOR OUTPUT p: its fits, LML and
+                             gradients are those of the complete cases of that output (what the reference's search
+                             does per output, waveome/model_search.py:3034-3043), while all outputs keep sharing one
+                             batch.  0 (default): NaN is data and makes every evaluation of that column non-finite.
+                             wv_gram / wv_predict / wv_whitened_means answer WV_E_UNSUPPORTED on such a problem. */
 } wv_problem_caps;
 /* wv_problem_create_multi with explicit capacities (each at least what `specs` need; caps = NULL: exactly that). */
 int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,

@@ -45,7 +45,7 @@ class KernelSpec(C.Structure):
 
 class ProblemCaps(C.Structure):
     _fields_ = [("max_specs", C.c_int32), ("max_params", C.c_int32), ("max_feat", C.c_int32),
-                ("max_factors", C.c_int32), ("max_red", C.c_int32)]
+                ("max_factors", C.c_int32), ("max_red", C.c_int32), ("nan_is_missing", C.c_int32)]
 
 
 class LbfgsOpts(C.Structure):

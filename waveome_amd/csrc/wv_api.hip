@@ -293,8 +293,8 @@ void wv_problem_destroy(wv_problem* h) {
     if (g.h_spec) hipHostFree(g.h_spec);
   }
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
-                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.dspans, p.dspec_span, p.Kbuf32, p.Mbuf32,
-                  p.MTbuf32,
+                  p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.dspans, p.dspec_span, p.dmask,
+                  p.dnobs, p.Kbuf32, p.Mbuf32, p.MTbuf32,
                   p.Pbuf32};
   for (void* q : ptrs)
     if (q) hipFree(q);
@@ -390,7 +390,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     p.max_feat = std::max(p.max_feat, (int)caps->max_feat);
     p.max_fact = std::max(p.max_fact, (int)caps->max_factors);
     p.max_red = std::max(p.max_red, (int)caps->max_red);
-    p.any_multidim = true;  // (later structures may act on several columns: the general trace kernel)
+    if (caps->max_specs > n_specs) p.any_multidim = true;  // (later structures may act on several columns: the general trace kernel)
   }
   p.specs.reserve(p.spec_cap);
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
@@ -459,8 +459,47 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
   WV_HIP_TRY(hipMemset(p.dalpha, 0, sizeof(double) * Np * max_batch));
   WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * np * max_batch));
   WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-  WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, Y, sizeof(double) * N, sizeof(double) * N, P,
-                         y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  bool y_uploaded = false;
+  if (caps && caps->nan_is_missing) {
+    // NaN in column p of Y = row missing for output p (complete-case fits per output, all outputs in one batch):
+    // those rows become padding rows of that output's fits.  Nothing is allocated when no NaN is found.
+    std::vector<double> hY((size_t)N * P);
+    WV_HIP_TRY(hipMemcpy(hY.data(), Y, sizeof(double) * N * P, y_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    std::vector<uint8_t> mask((size_t)Np * P, 0);
+    std::vector<int32_t> nobs(P, 0);
+    bool any = false;
+    for (int c = 0; c < P; ++c)
+      for (int64_t i = 0; i < N; ++i) {
+        double& y = hY[(size_t)c * N + i];
+        if (y != y) {
+          y = 0.0;
+          any = true;
+        } else {
+          mask[(size_t)c * Np + i] = 1;
+          ++nobs[c];
+        }
+      }
+    if (any) {
+      for (int c = 0; c < P; ++c)
+        if (nobs[c] == 0) {
+          set_error("wv_problem_create_ex: an output column has no observed value");
+          return WV_E_BADARG;
+        }
+      if (hipMalloc((void**)&p.dmask, mask.size()) != hipSuccess || hipMalloc((void**)&p.dnobs, sizeof(int32_t) * P) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device allocation failed (missing-value masks)");
+        return WV_E_OOM;
+      }
+      WV_HIP_TRY(hipMemcpy(p.dmask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+      WV_HIP_TRY(hipMemcpy(p.dnobs, nobs.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice));
+      WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, hY.data(), sizeof(double) * N, sizeof(double) * N, P,
+                             hipMemcpyHostToDevice));
+      y_uploaded = true;
+    }
+  }
+  if (!y_uploaded)
+    WV_HIP_TRY(hipMemcpy2D(p.dY, sizeof(double) * Np, Y, sizeof(double) * N, sizeof(double) * N, P,
+                           y_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemcpy(p.dspec, hspecs.data(), sizeof(DevSpec) * n_specs, hipMemcpyHostToDevice));
   WV_HIP_TRY(hipMemset(p.dslotspec, 0, sizeof(int32_t) * max_batch));
   WV_HIP_TRY(hipMemset(p.dspec_span, 0xff, sizeof(int32_t) * p.spec_cap));  // -1: dense
@@ -518,6 +557,10 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.dmask) {
+    set_error("wv_gram: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
+    return WV_E_UNSUPPORTED;
+  }
   if (p.specs.size() != 1) {
     set_error("wv_gram: the problem holds several structures (only wv_fit_multi serves those)");
     return WV_E_UNSUPPORTED;
@@ -988,6 +1031,10 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.dmask) {
+    set_error("wv_predict: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
+    return WV_E_UNSUPPORTED;
+  }
   if (p.specs.size() != 1) {
     set_error("wv_predict: the problem holds several structures (only wv_fit_multi serves those)");
     return WV_E_UNSUPPORTED;
@@ -1092,6 +1139,10 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.dmask) {
+    set_error("wv_whitened_means: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
+    return WV_E_UNSUPPORTED;
+  }
   if (p.specs.size() != 1) {
     set_error("wv_whitened_means: the problem holds several structures (only wv_fit_multi serves those)");
     return WV_E_UNSUPPORTED;

@@ -534,20 +534,21 @@ __global__ void resid_kernel(const DevSpec* __restrict__ specs, const int32_t* _
                              const double* __restrict__ Y,
                              const int32_t* __restrict__ col, const double* __restrict__ theta,
                              double* __restrict__ r, int32_t* __restrict__ status, int64_t N,
-                             int64_t Npad, int slot0) {
+                             int64_t Npad, int slot0, const uint8_t* __restrict__ mask) {
   const int b = slot0 + blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Npad) return;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const double c = sp->mean_param >= 0 ? theta[(int64_t)b * sp->n_params + sp->mean_param] : 0.0;
-  r[(int64_t)b * Npad + i] = (i < N) ? Y[(int64_t)col[b] * Npad + i] - c : 0.0;
+  const bool seen = mask ? mask[(int64_t)col[b] * Npad + i] != 0 : i < N;  // (a missing output is a padding row)
+  r[(int64_t)b * Npad + i] = seen ? Y[(int64_t)col[b] * Npad + i] - c : 0.0;
   if (i == 0) status[b] = 0;
 }
 
 void launch_resid(Problem& p, hipStream_t st, int slot0, int nb) {
   dim3 grid((unsigned)((p.Npad + 255) / 256), nb);
   hipLaunchKernelGGL(resid_kernel, grid, dim3(256), 0, st, p.dspec, p.dslotspec, p.dY, p.dcol, p.dtheta, p.dr,
-                     p.dstatus, p.N, p.Npad, slot0);
+                     p.dstatus, p.N, p.Npad, slot0, p.dmask);
 }
 
 // z = M r  (M lower triangular). One wave per row, 4 rows per wave, 16 rows per workgroup.
@@ -769,7 +770,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
                                                      const double* __restrict__ part,
                                                      double* __restrict__ out, int64_t N,
                                                      int64_t Npad, int nblk, int nwg, int part_stride,
-                                                     int out_stride, int slot0, int with_grad) {
+                                                     int out_stride, int slot0, int with_grad,
+                                                     const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ nobs) {
   __shared__ double sh[4];
   const int b = slot0 + blockIdx.x, tid = threadIdx.x;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -786,7 +789,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
   sa = block_sum(sa, sh);
   double* o = out + (int64_t)b * out_stride;
   if (tid == 0) {
-    o[0] = -0.5 * q - ld - 0.5 * (double)N * 1.8378770664093453;  // log(2 pi)
+    const double n_seen = nobs ? (double)nobs[col[b]] : (double)N;  // (complete cases of this output)
+    o[0] = -0.5 * q - ld - 0.5 * n_seen * 1.8378770664093453;  // log(2 pi)
     o[1] = q;
     o[2] = ld;
   }
@@ -818,7 +822,7 @@ void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad
   p.timer.begin(st, ST_REDUCE);
   hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dslotspec, p.dz, p.dalpha, p.dlogdet,
                      p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p, nb), trace_part_stride(p), p.out_stride, slot0,
-                     with_grad ? 1 : 0);
+                     with_grad ? 1 : 0, p.dcol, p.dmask ? p.dnobs : nullptr);
   p.timer.end(st);
 }
 

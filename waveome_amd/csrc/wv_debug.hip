@@ -234,6 +234,10 @@ int32_t wv_dbg_stage(wv_problem* h, int32_t col, const double* theta, int32_t wh
     return WV_E_BADARG;
   }
   Problem& p = h->p;
+  if (p.dmask) {
+    set_error("wv_dbg_stage: the problem has missing outputs (nan_is_missing)");
+    return WV_E_UNSUPPORTED;
+  }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   Group& g = p.groups[0];
   hipStream_t st = g.stream;

@@ -158,6 +158,10 @@ struct Problem {
   int n_span_tables = 0;
   int32_t* dspans = nullptr;          // [D][Npad / 64][2]
   int32_t* dspec_span = nullptr;      // [spec_cap]
+  // missing outputs (wv_problem_caps::nan_is_missing): per output column the rows that are observed (1) - masked
+  // rows are treated like padding rows (identity row of K_y, zero residual, no gradient weight) - and their count
+  uint8_t* dmask = nullptr;           // [P][Npad], null when nothing is missing
+  int32_t* dnobs = nullptr;           // [P]
   int np_stride = 0, max_feat = 0;
   int32_t* dslotspec = nullptr;  // [max_batch]
   int64_t N = 0, Npad = 0;

@@ -451,12 +451,15 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
                                                    int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
                                                    int tpw, int write_upper, uint64_t term_mask, double diag_override,
                                                    const int32_t* __restrict__ spans,
-                                                   const int32_t* __restrict__ spec_span) {
+                                                   const int32_t* __restrict__ spec_span,
+                                                   const int32_t* __restrict__ col,
+                                                   const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const double* th = theta_all + (int64_t)b * sp->n_params;
   R* K = Kall + (int64_t)b * Npad * Npad;
+  const uint8_t* seen = mask ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
   const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
   const int tid = threadIdx.x;
   double* tab = smem;
@@ -485,16 +488,23 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
       __syncthreads();
       kernel_sum_tile(sp, t, term_mask, sum);
     }
+    bool live_j[4];  // (padding rows and rows whose output is missing are identity rows / columns of K_y)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
+      live_j[c] = seen ? seen[j] != 0 : j < N;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
+      const bool live_i = seen ? seen[i] != 0 : i < N;
       double v[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
         double x = sum[a][c];
         if (i == j) x += noise;
-        if (i >= N || j >= N) x = (i == j) ? 1.0 : 0.0;  // identity padding
+        if (!live_i || !live_j[c]) x = (i == j) ? 1.0 : 0.0;  // identity padding
         v[c] = x;
       }
       store4(K + i * Npad + (int64_t)tj * GT + 4 * t.tx, v);
@@ -594,7 +604,9 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
                                                     double* __restrict__ part, int64_t N,
                                                     int64_t Npad, int max_feat, int max_fact, int slot0, int ntiles,
                                                     int tpw, int part_stride, const int32_t* __restrict__ spans,
-                                                    const int32_t* __restrict__ spec_span) {
+                                                    const int32_t* __restrict__ spec_span,
+                                                    const int32_t* __restrict__ col,
+                                                    const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
   };
 
   const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
+  const uint8_t* seen = mask ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
   for (int tt = 0; tt < tpw; ++tt) {
     const int tile = blockIdx.x * tpw + tt;
     if (tile >= ntiles) break;
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
       for (int c = 0; c < 4; ++c) {
         const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
         double m = (i > j) ? 1.0 : ((i == j) ? 0.5 : 0.0);
-        if (i >= N || j >= N) m = 0.0;
+        if (seen ? (seen[i] == 0 || seen[j] == 0) : (i >= N || j >= N)) m = 0.0;
         w[a][c] = m * (ai * aj[c] - kv[c]);
         if (i == j) snoise += w[a][c];
       }
@@ -716,7 +729,7 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
   dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
   hipLaunchKernelGGL(gram_kernel<R>, grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask,
-                     diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span);
+                     diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask);
 }
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
@@ -750,7 +763,7 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
 #define WV_TRACE_LAUNCH(RT, MU, KBUF)                                                                              \
   hipLaunchKernelGGL((trace_kernel<RT, MU>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
                      p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p), \
-                     p.n_span_tables ? p.dspans : nullptr, p.dspec_span)
+                     p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.f32) {

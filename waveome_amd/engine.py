@@ -90,10 +90,14 @@ class Context:
 class Problem:
     def __init__(self, ctx: Context, X, Y, spec: ModelSpec, max_batch: int = 8,
                  x_device_ptr: Optional[int] = None, y_device_ptr: Optional[int] = None,
-                 shape: Optional[Sequence[int]] = None, capacity: Optional[dict] = None):
+                 shape: Optional[Sequence[int]] = None, capacity: Optional[dict] = None,
+                 nan_is_missing: bool = False):
         """X: (N, D) array, Y: (N, P) array (one column per output).  Alternatively pass raw device
         pointers (x_device_ptr -> N x D row-major, y_device_ptr -> P x N row-major) with
-        shape=(N, D, P), e.g. buffers filled by an RCCL broadcast."""
+        shape=(N, D, P), e.g. buffers filled by an RCCL broadcast.
+        nan_is_missing: a NaN in Y[:, p] marks that row as missing for output p - fits, LML and gradients of that
+        output are those of its complete cases (the reference's per-output filter, model_search.py:3034-3043) while
+        all outputs keep sharing one batch; gram / predict / component means are then refused."""
         self.ctx, self.lib = ctx, ctx.lib
         # a list of specs makes a multi-structure problem (fit_multi only): tasks of different kernel
         # structures share the workspace and one work queue
@@ -118,10 +122,11 @@ class Problem:
             self._X = X
             xp, yp, xd, yd = C.c_void_p(X.ctypes.data), C.c_void_p(self._Yt.ctypes.data), 0, 0
         self.N, self.D, self.P, self.max_batch = N, D, P, int(max_batch)
-        if capacity is not None:
+        if capacity is not None or nan_is_missing:
             # room for structures added later (add_spec): max_specs / max_params / max_feat / max_factors / max_red
-            caps = _lib.ProblemCaps(**{k: int(capacity.get(k, 0)) for k in
+            caps = _lib.ProblemCaps(**{k: int((capacity or {}).get(k, 0)) for k in
                                        ("max_specs", "max_params", "max_feat", "max_factors", "max_red")})
+            caps.nan_is_missing = 1 if nan_is_missing else 0
             arr = (C.POINTER(_lib.KernelSpec) * len(self.specs))(*[C.pointer(cs) for cs in self._cspecs])
             _lib.check(self.lib.wv_problem_create_ex(ctx.handle, xp, N, D, yp, P, arr, len(self.specs), C.byref(caps),
                                                      int(max_batch), xd, yd, C.byref(self.handle)),

@@ -309,8 +309,17 @@ class GpuScorer:
 
         # `shared`: the inputs as parallel.broadcast_inputs left them (device tensors of the RCCL broadcast under
         # nccl); otherwise the arrays are broadcast here so that every rank scores on rank 0's data
-        self.shared = shared if shared is not None else parallel.broadcast_inputs(X, Y)
+        # Missing values, as full_kernel_search treats them (model_search.py:3034-3043: per output, the rows where
+        # every input and that output are observed; GPSearch itself refuses NaN, so only direct callers get here):
+        # rows with a missing input go for every output; a missing output value masks the row for that output only,
+        # on the device (wv_problem_caps::nan_is_missing), so all outputs keep sharing one batch.
+        if shared is None:
+            X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+            x_ok = ~np.isnan(X).any(axis=1)
+            shared = parallel.broadcast_inputs(X[x_ok], Y[x_ok])
+        self.shared = shared
         self.X, self.Y = self.shared.X, self.shared.Y
+        self.nan_is_missing = bool(np.isnan(self.Y).any())
         self.ctx = context or default_context()
         self.max_batch = max_batch
         self.num_restart, self.random_seed = max(1, int(num_restart)), random_seed
@@ -375,7 +384,7 @@ class GpuScorer:
                         pts = restart_points(sp.n_trainable, R, random_seed=self.random_seed)
                         U0[rows, :sp.n_trainable] = np.tile(pts, (len(rows) // R, 1))
                 mb = self.max_batch or min(len(rep), _default_batch(N))
-                prob = self.shared.problem(self.ctx, sp_list, max(1, mb))
+                prob = self.shared.problem(self.ctx, sp_list, max(1, mb), nan_is_missing=self.nan_is_missing)
                 try:
                     res = prob.fit_multi(cols_r, sidx_r, U0, self.opts)
                 finally:
@@ -394,7 +403,7 @@ class GpuScorer:
                 sp = specs[mine[rows[0]]]
                 cols = np.array([tasks[mine[r]][0] for r in rows], dtype=np.int32)
                 mb = self.max_batch or min(len(rows), _default_batch(N))
-                prob = self.shared.problem(self.ctx, sp, max(1, mb))
+                prob = self.shared.problem(self.ctx, sp, max(1, mb), nan_is_missing=self.nan_is_missing)
                 try:
                     res = prob.fit(cols, np.tile(sp.unconstrain(), (len(rows), 1)), self.opts)
                 finally:
@@ -464,7 +473,8 @@ class _SearchSession:
         self.mb = scorer.max_batch or _default_batch(self.N)
 
     def _open(self, first_spec: ModelSpec):
-        self.prob = self.sc.shared.problem(self.sc.ctx, [first_spec], max(1, self.mb), capacity=self.CAPS)
+        self.prob = self.sc.shared.problem(self.sc.ctx, [first_spec], max(1, self.mb), capacity=self.CAPS,
+                                           nan_is_missing=self.sc.nan_is_missing)
         self.queue = self._FitQueue(self.prob, self.sc.opts, width=self.CAPS["max_params"])
 
     def request(self, col: int, kernel, callback):

@@ -114,7 +114,7 @@ class SharedInputs:
             Xt, Yt = self._Xt[idx].contiguous(), self._Yt[:, idx].contiguous()
         return SharedInputs(np.ascontiguousarray(self.X[perm]), np.ascontiguousarray(self.Y[perm]), Xt, Yt)
 
-    def problem(self, ctx, spec, max_batch, capacity=None):
+    def problem(self, ctx, spec, max_batch, capacity=None, nan_is_missing=False):
         """engine.Problem on these inputs: from the broadcast's device tensors when they live on ctx's GPU
         (device-to-device copy inside wv_problem_create), from the host copies otherwise."""
         from .engine import Problem
@@ -122,8 +122,9 @@ class SharedInputs:
         if self._Xt is not None and self._Xt.is_cuda and self._Xt.device.index == ctx.device:
             N, D = self.X.shape
             return Problem(ctx, None, None, spec, max_batch=max_batch, x_device_ptr=self._Xt.data_ptr(),
-                           y_device_ptr=self._Yt.data_ptr(), shape=(N, D, self.Y.shape[1]), capacity=capacity)
-        return Problem(ctx, self.X, self.Y, spec, max_batch=max_batch, capacity=capacity)
+                           y_device_ptr=self._Yt.data_ptr(), shape=(N, D, self.Y.shape[1]), capacity=capacity,
+                           nan_is_missing=nan_is_missing)
+        return Problem(ctx, self.X, self.Y, spec, max_batch=max_batch, capacity=capacity, nan_is_missing=nan_is_missing)
 
 
 def broadcast_inputs(X: np.ndarray, Y: np.ndarray, src: int = 0, device=None) -> SharedInputs:
