@@ -442,7 +442,7 @@ __device__ inline bool tile_is_zero(const int32_t* __restrict__ span, int ti, in
 constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup) ...
 constexpr int FEW_FITS = 8;  // ... but ONE with at most this many fits in flight: more, shorter workgroups (latency regime)
 
-template <typename R>
+template <typename R, bool MASKED>  // MASKED: missing outputs (row masks per output column), see trace_kernel
 __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
                                                    const int32_t* __restrict__ slot_spec,
                                                    const double* __restrict__ F, const double* __restrict__ FC,
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const double* th = theta_all + (int64_t)b * sp->n_params;
   R* K = Kall + (int64_t)b * Npad * Npad;
-  const uint8_t* seen = mask ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
+  const uint8_t* seen = MASKED ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
   const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
   const int tid = threadIdx.x;
   double* tab = smem;
@@ -492,12 +492,12 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
-      live_j[c] = seen ? seen[j] != 0 : j < N;
+      live_j[c] = MASKED ? seen[j] != 0 : j < N;
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
-      const bool live_i = seen ? seen[i] != 0 : i < N;
+      const bool live_i = MASKED ? seen[i] != 0 : i < N;
       double v[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -594,7 +594,9 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // MULTI = false: every factor of every structure acts on ONE column (what full_kernel_build produces): the paths that
 // keep 4 x 4 distance arrays are not instantiated, 186 instead of 230 VGPRs, and the kernel is held to 168 (3 waves per
 // SIMD instead of 2; 11 VGPRs spill) - the pass is latency-bound, not issue-bound (section 4.0 of DESIGN.md).
-template <typename R, bool MULTI>
+// MASKED: the problem has missing outputs (row masks per output column); its own instantiation so that the common case
+// keeps the register budget it was tuned for.
+template <typename R, bool MULTI, bool MASKED>
 __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ F, const double* __restrict__ FC,
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
   };
 
   const int32_t* span = block_span_table(spans, spec_span, slot_spec[b], Npad);
-  const uint8_t* seen = mask ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
+  const uint8_t* seen = MASKED ? mask + (int64_t)col[b] * Npad : nullptr;  // observed rows of this fit's output
   for (int tt = 0; tt < tpw; ++tt) {
     const int tile = blockIdx.x * tpw + tt;
     if (tile >= ntiles) break;
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
       for (int c = 0; c < 4; ++c) {
         const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
         double m = (i > j) ? 1.0 : ((i == j) ? 0.5 : 0.0);
-        if (seen ? (seen[i] == 0 || seen[j] == 0) : (i >= N || j >= N)) m = 0.0;
+        if (MASKED ? (seen[i] == 0 || seen[j] == 0) : (i >= N || j >= N)) m = 0.0;
         w[a][c] = m * (ai * aj[c] - kv[c]);
         if (i == j) snoise += w[a][c];
       }
@@ -727,9 +729,13 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
                           double diag) {
   const int tpw = gram_tpw(nb);
   dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
-  hipLaunchKernelGGL(gram_kernel<R>, grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,
-                     p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask,
-                     diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask);
+#define WV_GRAM_LAUNCH(MA)                                                                                              \
+  hipLaunchKernelGGL((gram_kernel<R, MA>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,   \
+                     p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask, \
+                     diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
+  if (p.dmask) WV_GRAM_LAUNCH(true);
+  else WV_GRAM_LAUNCH(false);
+#undef WV_GRAM_LAUNCH
 }
 
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
@@ -760,10 +766,15 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   dim3 grid(trace_nwg(p, nb), nb), blk(256);
   size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
-#define WV_TRACE_LAUNCH(RT, MU, KBUF)                                                                              \
-  hipLaunchKernelGGL((trace_kernel<RT, MU>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
+#define WV_TRACE_LAUNCH_M(RT, MU, MA, KBUF)                                                                        \
+  hipLaunchKernelGGL((trace_kernel<RT, MU, MA>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
                      p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p), \
                      p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
+#define WV_TRACE_LAUNCH(RT, MU, KBUF)              \
+  do {                                             \
+    if (p.dmask) WV_TRACE_LAUNCH_M(RT, MU, true, KBUF); \
+    else WV_TRACE_LAUNCH_M(RT, MU, false, KBUF);   \
+  } while (0)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.f32) {
@@ -774,6 +785,7 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
     else WV_TRACE_LAUNCH(double, false, p.Kbuf);
   }
 #undef WV_TRACE_LAUNCH
+#undef WV_TRACE_LAUNCH_M
   p.timer.end(st);
   p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
