@@ -28,7 +28,7 @@ PEAK_FP64_MATRIX_TFLOPS = 78.6  # AMD MI355X datasheet FP64 matrix; measured v_m
                                 # back-to-back issue: 73.4 TF (tools/probe_rates.py), the local guide
                                 # lists no f64 matrix rate
 N_HEAD, D_HEAD = 2048, 3
-GEMM_STAGES = ("chol_trsm", "chol_trailing_syrk", "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm")
+GEMM_STAGES = ("chol_trsm", "chol_trailing_syrk", "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "lauum_gemm_few_fits")
 DOMINANT_STAGE = "lauum_gemm"  # K_y^-1 = M'M: the single largest launch (N^3/3 FLOP per fit per evaluation)
 
 
@@ -378,7 +378,10 @@ def main():
                                          zip(*np.unique(table[:, 4], return_counts=True))}},
             "roofline": {"bound": "mfma",
                          "kernel": f"gemm_f64_kernel<false, false, 128, 2, 0, 1> + its diagonal-tile launch <..., 0, 5> "
-                                   f"({DOMINANT_STAGE}: K_y^-1 = M'M, one pair of launches per evaluation round)",
+                                   f"({DOMINANT_STAGE}: K_y^-1 = M'M; every evaluation round with at least 4 fits in "
+                                   f"flight launches it once - with 16 or more as this pair of launches, below that "
+                                   f"as <..., 0, 1> alone; rounds with fewer fits use the small-tile kernel and are "
+                                   f"not counted here)",
                          "achieved": ach, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

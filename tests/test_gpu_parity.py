@@ -332,7 +332,8 @@ def test_stage_timers_report(ctx):
     prob.value_grad([0, 1, 2, 0], np.tile(ms.unconstrain(), (4, 1)))
     t = prob.stage_times()
     assert t["chol_trailing_syrk"]["launches"] > 0 and t["chol_trailing_syrk"]["ms"] > 0
-    assert t["lauum_gemm"]["flops"] > 0
+    # (few fits in flight: K_y^-1 = M'M runs on the small tile and is reported as its own stage)
+    assert t["lauum_gemm"]["flops"] + t["lauum_gemm_few_fits"]["flops"] > 0
     prob.close()
 
 

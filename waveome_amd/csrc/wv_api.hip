@@ -18,7 +18,8 @@ namespace wv {
 
 const char* const kStageNames[ST_COUNT] = {
     "gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
-    "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce"};
+    "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce",
+    "lauum_gemm_few_fits"};
 
 // ---------------- stage timer ----------------
 void StageTimer::begin(hipStream_t s, int stage) {

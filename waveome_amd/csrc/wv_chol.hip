@@ -166,6 +166,8 @@ __device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restr
   for (int jb = 0; jb < 16; ++jb) {
     R* dbuf = dinfo + DINFO * jb;
     if (ty == jb && tx == jb) {
+      // 4 x 4 factor of the diagonal block: the critical path of the whole leaf (four dependent rsqrt per step).  (An
+      // LDL' recurrence on v_rcp_f64 reciprocals with the four rsqrt hanging off the chain measured 14 % SLOWER.)
       R inv[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -1144,13 +1146,16 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
   a.tri = 1; a.tri_off = 0; a.tag = 1;
   with_spans(a, p, slot0, 0, 0, 0);
-  p.timer.begin(st, ST_LAUUM);
-  // 128-wide tiles (its own kernel symbols: off-diagonal + diagonal-tile launch) unless so few fits are in flight
-  // that the two dependent launches and their few long tiles are the cost: then 64-wide tiles, one launch
+  // 128-wide tiles (its own kernel symbols <..., 0, 1> and, for the diagonal-tile launch, <..., 0, 5>) unless so few
+  // fits are in flight that a few long tiles are the cost: then the small tile, one launch (timed as its own stage, so
+  // that ST_LAUUM's launches are exactly those of the two named symbols)
   static const int forced = [] { const char* e = getenv("WV_LAUUM_TILE"); return e ? atoi(e) : 0; }();  // (experiments)
-  launch_gemm(st, a, false, false, forced ? forced : pick_bn(Np, Np, nb, true));
+  const int tile = forced ? forced : pick_bn(Np, Np, nb, true);
+  const int stage = tile == 128 ? ST_LAUUM : ST_LAUUM_FEW;
+  p.timer.begin(st, stage);
+  launch_gemm(st, a, false, false, tile);
   p.timer.end(st);
-  p.timer.work(ST_LAUUM, nb * (double)Np * Np * Np / 3.0, 0.0);
+  p.timer.work(stage, nb * (double)Np * Np * Np / 3.0, 0.0);
 }
 
 void lauum(Problem& p, hipStream_t st, int slot0, int nb) {

@@ -100,7 +100,9 @@ using GemmArgsF = GemmArgsT<float>;  // float32 storage path (wv_gemm32.hip)
 
 enum Stage {
   ST_GRAM = 0, ST_POTRF_DIAG, ST_CHOL_TRSM, ST_CHOL_PANEL, ST_CHOL_TRAIL, ST_TRTRI_A, ST_TRTRI_B,
-  ST_LAUUM, ST_SOLVE, ST_TRACE, ST_REDUCE, ST_COUNT
+  ST_LAUUM, ST_SOLVE, ST_TRACE, ST_REDUCE,
+  ST_LAUUM_FEW,  // K_y^-1 = M'M on the small / 64-wide tiles of the few-fits regime (other kernel symbols than ST_LAUUM's)
+  ST_COUNT
 };
 extern const char* const kStageNames[ST_COUNT];
 

@@ -265,7 +265,8 @@ class Problem:
 
     # ---- timing ----
     STAGES = ("gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
-              "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce")
+              "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce",
+              "lauum_gemm_few_fits")
 
     def timing(self, on, stages=None):
         """on=False: off; on=True: all stages, or only the named `stages`."""
