@@ -1164,7 +1164,6 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
   const int64_t mat = p.Npad * p.Npad;
   double* K0 = p.Kbuf + (int64_t)g.slot0 * mat;
   double* q_mu = p.dr + (int64_t)g.slot0 * p.Npad;   // re-use r
-  double* out = p.dz + (int64_t)g.slot0 * p.Npad;    // re-use z
   const uint64_t all = p.spec.n_terms() >= 64 ? ~0ull : ((1ull << p.spec.n_terms()) - 1ull);
   const double c = p.spec.mean_param >= 0 ? theta[p.spec.mean_param] : 0.0;
   // q_mu = chol(K + jitter I)' alpha   (whitened optimum of the SVGP with Z = X)
