@@ -378,10 +378,9 @@ def main():
                                          zip(*np.unique(table[:, 4], return_counts=True))}},
             "roofline": {"bound": "mfma",
                          "kernel": f"gemm_f64_kernel<false, false, 128, 2, 0, 1> + its diagonal-tile launch <..., 0, 5> "
-                                   f"({DOMINANT_STAGE}: K_y^-1 = M'M; every evaluation round with at least 4 fits in "
-                                   f"flight launches it once - with 16 or more as this pair of launches, below that "
-                                   f"as <..., 0, 1> alone; rounds with fewer fits use the small-tile kernel and are "
-                                   f"not counted here)",
+                                   f"({DOMINANT_STAGE}: K_y^-1 = M'M, one pair of launches per evaluation round; the "
+                                   f"rounds of a step's tail with fewer than ~30 fits in flight run this product on "
+                                   f"the small-tile kernel, are timed as lauum_gemm_few_fits and are not counted here)",
                          "achieved": ach, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP64_MATRIX_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

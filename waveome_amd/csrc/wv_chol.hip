@@ -950,14 +950,17 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 //   M21 = -M22 T                      (contraction k <= row)
 // L itself is never assembled: log|K_y| comes from the diagonal blocks, z = M r, alpha = M' z.
 // ---------------------------------------------------------------------------------------
-// Tile for a product with a rows x cols output over nb matrices (launch_gemm's tile code): 128 x 128 unless so few
-// tiles exist that most of the 512 resident workgroup slots would idle - then the small 64 x 64 tile (four times the
-// workgroups; measured better than 128 x 64 wherever that was: WV_SMALL_FILL = 1024 leaves 128 x 64 no window).
-// That is the small-batch, large-N end: the tail of a job, a single fit.  WV_BN_FILL=0 restores 128 everywhere;
-// WV_SMALL_FILL=0 stops at 128 x 64.
+// Tile for a product with a rows x cols output over nb matrices (launch_gemm's tile code): 128 x 128 when the launch
+// has at least 4096 such tiles (eight per resident workgroup slot), else the small 64 x 64 tile - four times the
+// workgroups, which balance better over the 256 CUs when the tiles are few (one fit in flight: every product of the
+// recursion) or the launch is only a few waves of workgroups deep (full batches: the two lowest levels of the
+// recursion).  Measured (ms per round, thresholds 512 -> 4096): one fit N = 2048 3.72 -> 2.06 with the small tile at
+// all; 16 fits 5.42 -> 5.08, 128 fits 27.5 -> 26.6, 512 fits 101.8 -> 100.6.  The 128 x 64 tile of round 1 has no
+// window left (WV_SMALL_FILL = 2 x WV_BN_FILL); WV_BN_FILL=0 restores 128 x 128 everywhere, WV_SMALL_FILL=0 stops at
+// 128 x 64.
 static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
-  static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 512; }();
-  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 1024; }();
+  static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 4096; }();
+  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 8192; }();
   int64_t tiles = ((rows + 127) / 128) * ((cols + 127) / 128);
   if (lower_only) tiles = (tiles + (rows + 127) / 128) / 2;
   if (tiles * nb >= fill) return cols <= 64 ? 64 : 128;
