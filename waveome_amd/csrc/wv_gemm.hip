@@ -27,6 +27,7 @@
 //   K-contiguous operand  [rows][16+2]   (row stride 18 doubles: 18*r mod 32 distinct, even)
 //   K-strided   operand   [16][rows+16]  (row stride = 16 mod 32 doubles)
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -297,22 +298,37 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
         if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
         else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * WCOLS, brot, fr, fk);
       } else {
+        // One chunk for the A fragments [I0, I1) of the wave (16 rows each): all four, except where a triangular
+        // operand leaves whole fragments zero - in K_y^-1 = M'M (TAG 1) A(m, k) = M[k][m] vanishes for k < m, so in
+        // the first 64 k of a wave's range only the fragments with rows <= k take part (10 of 16 fragment-chunks).
+        auto chunk = [&](auto i0c, auto i1c) {
+          constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
 #pragma unroll OCC == 1 ? 4 : 1
-        for (int s = 0; s < KC / 4; ++s) {
-          double af[4];
+          for (int s = 0; s < KC / 4; ++s) {
+            double af[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[i] = NOLDS ? 1.0 + i + lane * 1e-3 : a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
+            for (int i = I0; i < I1; ++i) af[i] = NOLDS ? 1.0 + i + lane * 1e-3 : a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * WCOLS + j * 16 + brot[r], s * 4 + fk)];
+              for (int r = 0; r < 4; ++r) {
+                const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * WCOLS + j * 16 + brot[r], s * 4 + fk)];
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+                for (int i = I0; i < I1; ++i)
+                  acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf, acc[i][j][r], 0, 0, 0);
+              }
             }
           }
+        };
+        using std::integral_constant;
+        int live = 4;
+        if constexpr ((TAG & 1) != 0 && !SMALL) {
+          if (g.klo_mode == 1) live = min(4, (kc0 - (m0 + wm * 64) - g.koff) / 16 + 1);
         }
+        if (live >= 4) chunk(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        else if (live == 3) chunk(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+        else if (live == 2) chunk(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+        else chunk(integral_constant<int, 0>{}, integral_constant<int, 1>{});
       }
     }
     if (c + 1 < nchunk) {
