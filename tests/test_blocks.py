@@ -218,3 +218,19 @@ def test_kernel_sweep_on_shuffled_longitudinal_data():
     a, b = tables
     np.testing.assert_allclose(a["loss"].to_numpy(), b["loss"].to_numpy(), rtol=1e-7, atol=1e-7)
     ctx.close()
+
+
+def test_shared_inputs_sorted_by_permutes_the_broadcast_tensors_too():
+    """Under torch.distributed the inputs also live in the tensors the broadcast filled (device tensors with RCCL):
+    sorting must permute those the same way (X as N x D, Y as P x N)."""
+    torch = pytest.importorskip("torch")
+    from waveome_amd.parallel import SharedInputs
+
+    rng = np.random.default_rng(9)
+    X = np.column_stack([rng.normal(size=30), rng.integers(0, 4, 30).astype(float)])
+    Y = rng.normal(size=(30, 3))
+    sh = SharedInputs(X, Y, torch.from_numpy(X.copy()), torch.from_numpy(np.ascontiguousarray(Y.T)))
+    so = sh.sorted_by(1)
+    np.testing.assert_array_equal(so._Xt.numpy(), so.X)
+    np.testing.assert_array_equal(so._Yt.numpy(), so.Y.T)
+    assert so._Xt.is_contiguous() and so._Yt.is_contiguous()
