@@ -968,6 +968,14 @@ static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
   return 32;
 }
 
+// Size of the left child of a recursion node of n rows (a multiple of 64): half of n in units of the fused 128-leaf
+// when n is a multiple of 128 - so that e.g. 384 = 128 + 256 ends in three fused leaves instead of 192 + 192 =
+// 2 x (64-leaf + 128-leaf) with their extra small products - else half in units of 64.
+static int64_t split_point(int64_t n) {
+  if (n % (2 * NB) == 0) return (n / (2 * NB) / 2) * (2 * NB);
+  return (n / NB / 2) * NB;
+}
+
 template <typename R>
 static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, int64_t n) {
   if (n == NB) {
@@ -980,7 +988,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     return;
   }
   const int64_t Np = p.Npad, mat = Np * Np;
-  const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
+  const int64_t h1 = split_point(n), h2 = n - h1;
   const MatBufs<R> mb = mat_bufs<R>(p);
   R* K0 = mb.K + (int64_t)slot0 * mat;
   R* M0 = mb.M + (int64_t)slot0 * mat;
@@ -1086,7 +1094,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     return;
   }
-  const int64_t h1 = (n / NB / 2) * NB, h2 = n - h1;
+  const int64_t h1 = split_point(n), h2 = n - h1;
   R* K0 = mb.K + (int64_t)slot0 * mat;
   R* MT0 = mb.MT + (int64_t)slot0 * mat;
   R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();
