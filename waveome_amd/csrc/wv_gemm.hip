@@ -298,18 +298,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
         if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
         else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * WCOLS, brot, fr, fk);
       } else {
-        // One chunk for the A fragments [I0, I1) of the wave (16 rows each): all four, except where a triangular
-        // operand leaves whole fragments zero - in K_y^-1 = M'M (TAG 1) A(m, k) = M[k][m] vanishes for k < m, so in
-        // the first 64 k of a wave's range only the fragments with rows <= k take part (10 of 16 fragment-chunks).
-        auto chunk = [&](auto i0c, auto i1c) {
+        // One chunk for the A fragments [I0, I1) (16 rows each) and B column sets [J0, J1) (16 columns each) of the
+        // wave: all of them, except where a triangular operand leaves whole fragments zero in the 64 k next to the
+        // wave's own rows / columns (10 of 16 fragment-chunks there).  Which side and which end depends on the product
+        // and is fixed per instantiation (FAM), so that each kernel carries three partial variants, not twelve:
+        //   1  K_y^-1 = M'M (TAG 1)   A(m, k) = M[k][m]    zero for k < m   -> A fragments [0, live)
+        //   2  M21 = -M22 T (TOUT 2)  A(m, k) = M22[m][k]  zero for k > m   -> A fragments [4 - live, 4)
+        //   3  S = A21 M11' (TOUT 1)  B(n, k) = M11[n][k]  zero for k > n   -> B column sets [4 - live, 4)
+        //   4  T = S M11 (plain)      B(n, k) = M11[k][n]  zero for k < n   -> B column sets [0, live)
+        auto chunk = [&](auto i0c, auto i1c, auto j0c, auto j1c) {
           constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+          constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
 #pragma unroll OCC == 1 ? 4 : 1
           for (int s = 0; s < KC / 4; ++s) {
             double af[4];
 #pragma unroll
             for (int i = I0; i < I1; ++i) af[i] = NOLDS ? 1.0 + i + lane * 1e-3 : a_s[TA::at(wm * 64 + i * 16 + fr, s * 4 + fk)];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = J0; j < (J1 < NJ ? J1 : NJ); ++j) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const double bf = NOLDS ? 0.5 + j + r + lane * 1e-3 : b_s[TB::at(wn * WCOLS + j * 16 + brot[r], s * 4 + fk)];
@@ -321,14 +327,36 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
           }
         };
         using std::integral_constant;
+        using c0 = integral_constant<int, 0>; using c1 = integral_constant<int, 1>; using c2 = integral_constant<int, 2>;
+        using c3 = integral_constant<int, 3>; using c4 = integral_constant<int, 4>;
+        constexpr int FAM = (SMALL || BN != 128 || NOLDS) ? 0 : (TAG & 1) ? 1 : TOUT == 2 ? 2 : TOUT == 1 ? 3 : TAG == 0 ? 4 : 0;
         int live = 4;
-        if constexpr ((TAG & 1) != 0 && !SMALL) {
-          if (g.klo_mode == 1) live = min(4, (kc0 - (m0 + wm * 64) - g.koff) / 16 + 1);
+        if (g.koff == 0) {
+          const int wr = m0 + wm * 64, wc = n0 + wn * WCOLS;
+          if (FAM == 1 && g.klo_mode == 1) live = min(4, (kc0 - wr) / 16 + 1);
+          if (FAM == 2 && g.khi_mode == 1) live = 4 - min(3, max(0, (kc0 - wr) / 16));
+          if (FAM == 3 && g.khi_mode == 2) live = 4 - min(3, max(0, (kc0 - wc) / 16));
+          if (FAM == 4 && g.klo_mode == 2) live = min(4, (kc0 - wc) / 16 + 1);
         }
-        if (live >= 4) chunk(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-        else if (live == 3) chunk(integral_constant<int, 0>{}, integral_constant<int, 3>{});
-        else if (live == 2) chunk(integral_constant<int, 0>{}, integral_constant<int, 2>{});
-        else chunk(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        if (FAM == 0 || live >= 4) {
+          chunk(c0{}, c4{}, c0{}, c4{});
+        } else if constexpr (FAM == 1) {
+          if (live == 3) chunk(c0{}, c3{}, c0{}, c4{});
+          else if (live == 2) chunk(c0{}, c2{}, c0{}, c4{});
+          else chunk(c0{}, c1{}, c0{}, c4{});
+        } else if constexpr (FAM == 2) {
+          if (live == 3) chunk(c1{}, c4{}, c0{}, c4{});
+          else if (live == 2) chunk(c2{}, c4{}, c0{}, c4{});
+          else chunk(c3{}, c4{}, c0{}, c4{});
+        } else if constexpr (FAM == 3) {
+          if (live == 3) chunk(c0{}, c4{}, c1{}, c4{});
+          else if (live == 2) chunk(c0{}, c4{}, c2{}, c4{});
+          else chunk(c0{}, c4{}, c3{}, c4{});
+        } else if constexpr (FAM == 4) {
+          if (live == 3) chunk(c0{}, c4{}, c0{}, c3{});
+          else if (live == 2) chunk(c0{}, c4{}, c0{}, c2{});
+          else chunk(c0{}, c4{}, c0{}, c1{});
+        }
       }
     }
     if (c + 1 < nchunk) {
