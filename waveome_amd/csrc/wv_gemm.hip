@@ -329,7 +329,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
         using std::integral_constant;
         using c0 = integral_constant<int, 0>; using c1 = integral_constant<int, 1>; using c2 = integral_constant<int, 2>;
         using c3 = integral_constant<int, 3>; using c4 = integral_constant<int, 4>;
-        constexpr int FAM = (SMALL || BN != 128 || NOLDS) ? 0 : (TAG & 1) ? 1 : TOUT == 2 ? 2 : TOUT == 1 ? 3 : TAG == 0 ? 4 : 0;
+        // (the small tile's waves sit side by side, 16 columns each: its column sets are whole waves, already trimmed
+        //  by wkb / wke; its four A fragments are skipped like the big tile's - only M21 has its own small symbol)
+        constexpr int FAM = NOLDS ? 0 : SMALL ? (TOUT == 2 ? 2 : 0) : BN != 128 ? 0
+                            : (TAG & 1) ? 1 : TOUT == 2 ? 2 : TOUT == 1 ? 3 : TAG == 0 ? 4 : 0;
         int live = 4;
         if (g.koff == 0) {
           const int wr = m0 + wm * 64, wc = n0 + wn * WCOLS;
