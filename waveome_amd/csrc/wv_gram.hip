@@ -67,6 +67,27 @@ struct TileCtx {
   int ty, tx;
 };
 
+// exp2_64 forms its table address by OR: the table must start at offset 0 of the workgroup's LDS, i.e. the kernel must
+// have no static __shared__ data.  Checked once per kernel symbol on the host; a kernel that fails is not launched.
+template <typename Kern>
+static bool exp_table_at_lds_zero(Kern kernel) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // (cannot tell: the kernels in this file are written without static LDS)
+  }
+  if (a.sharedSizeBytes != 0) {
+    fail_launch("Gram / trace kernel has static LDS: the exp table is not at LDS offset 0");
+    return false;
+  }
+  return true;
+}
+template <auto Kernel>
+static bool exp_table_ok() {
+  static const bool ok = exp_table_at_lds_zero(Kernel);
+  return ok;
+}
+
 // Per-factor constants that depend on theta only - computed once per fit and evaluation (feature_kernel), not
 // per tile and thread: c[0] = element scale, c[1] = variance, c[2] / c[3] = what the lengthscale / period sums
 // of the gradient pass are multiplied by.
@@ -101,6 +122,9 @@ __device__ inline void factor_constants(const DevFactor& f, const double* __rest
 // factor by its degree-5 Taylor polynomial (|r ln2/64| <= 0.0054, truncation 3.5e-17), the middle one from the LDS
 // table - stored [j][lane & 31], so lane l of each 32-lane group reads dwords 2l, 2l+1 (mod 64) whatever its j:
 // conflict-free ds_read_b64.  ~2 ulp.  Arguments below ~ -2^31 saturate the integer conversion and underflow to 0.
+// `tab` = this lane's slice of the table (table base + (lane & 31) doubles).  The table is the first 16 KB of the
+// workgroup's LDS (offset 0: the kernels here have no static __shared__ data - launch_* check it once), so the entry's
+// address is (j << 8) OR-ed into the lane's: one v_and_or_b32 instead of and + add.
 __device__ inline double exp2_64(double t, const double* __restrict__ tab) {
   const double kd = rint(t);
   const double r = t - kd;
@@ -111,7 +135,10 @@ __device__ inline double exp2_64(double t, const double* __restrict__ tab) {
   p = fma(p, r, 5.86490495505617e-05);         // ^2 / 2!
   p = fma(p, r, 0.010830424696249145);         // ln2/64
   p = fma(p, r, 1.0);
-  return ldexp(tab[(k & 63) * 32] * p, k >> 6);
+  typedef const __attribute__((address_space(3))) double* lds_cdp;
+  const uint32_t lane_addr = (uint32_t)(size_t)(lds_cdp)tab;  // < 256: the lane's 8 bytes inside a table row
+  const uint32_t addr = (((uint32_t)k << 8) & 0x3f00u) | lane_addr;
+  return ldexp(*(lds_cdp)(size_t)addr * p, k >> 6);
 }
 
 __device__ inline double ipow(double b, int e) {
@@ -560,6 +587,7 @@ void launch_gram_rect(Problem& p, hipStream_t st, const double* dXnew, int64_t M
   const int tiles_n = (int)(p.Npad / GT);
   dim3 grid((unsigned)((Mpad / GT) * tiles_n)), blk(256);
   size_t sh = ((size_t)2 * p.hspec.n_feat * GT + EXPTAB_DOUBLES + 4 * p.hspec.n_factors) * sizeof(double);  // (structure 0)
+  if (!exp_table_ok<gram_rect_kernel>()) return;
   hipLaunchKernelGGL(gram_rect_kernel, grid, blk, sh, st, p.dspec, dXnew, p.dX, dtheta_row, out, Mrow, p.N,
                      p.Npad, p.D, tiles_n);
 }
@@ -730,11 +758,12 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
   const int tpw = gram_tpw(nb);
   dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
 #define WV_GRAM_LAUNCH(MA)                                                                                              \
+  if (exp_table_ok<gram_kernel<R, MA>>())                                                                               \
   hipLaunchKernelGGL((gram_kernel<R, MA>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,   \
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask, \
                      diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
-  if (p.dmask) WV_GRAM_LAUNCH(true);
-  else WV_GRAM_LAUNCH(false);
+  if (p.dmask) { WV_GRAM_LAUNCH(true); }
+  else { WV_GRAM_LAUNCH(false); }
 #undef WV_GRAM_LAUNCH
 }
 
@@ -767,13 +796,14 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
 #define WV_TRACE_LAUNCH_M(RT, MU, MA, KBUF)                                                                        \
+  if (exp_table_ok<trace_kernel<RT, MU, MA>>())                                                                     \
   hipLaunchKernelGGL((trace_kernel<RT, MU, MA>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
                      p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p), \
                      p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
 #define WV_TRACE_LAUNCH(RT, MU, KBUF)              \
   do {                                             \
-    if (p.dmask) WV_TRACE_LAUNCH_M(RT, MU, true, KBUF); \
-    else WV_TRACE_LAUNCH_M(RT, MU, false, KBUF);   \
+    if (p.dmask) { WV_TRACE_LAUNCH_M(RT, MU, true, KBUF); } \
+    else { WV_TRACE_LAUNCH_M(RT, MU, false, KBUF); }   \
   } while (0)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
