@@ -2,6 +2,7 @@
 inputs.  float64 tolerances are written next to each assertion.  Run with `-m gpu` on an MI355X."""
 import json
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -886,3 +887,59 @@ def test_random_kernel_trees_match_oracle(ctx, seed):
             continue
         assert loss[b] == pytest.approx(fo, rel=1e-9, abs=1e-8)
         np.testing.assert_allclose(grad[b], go, rtol=1e-6, atol=1e-6 * max(1.0, np.max(np.abs(go))))
+
+
+# ---------------------------------------------------------------- tile regimes
+_TILE_REGIME_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from waveome_amd import ModelSpec, kernels as K
+from waveome_amd.engine import Context, Problem
+
+rng = np.random.default_rng(5)
+N = 700  # Npad = 704 = 11 x 64: uneven splits, one lone 64-leaf
+X = rng.normal(size=(N, 3))
+Y = np.stack([np.sin(X[:, 0] * (1 + 0.3 * p)) + 0.3 * X[:, 1] + 0.1 * rng.normal(size=N) for p in range(3)], axis=1)
+kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),
+              K.Product([K.Periodic(K.SquaredExponential(active_dims=[0])), K.Lin(active_dims=[2])])])
+spec = ModelSpec(kern, 3, K.GaussianLikelihood(), K.ConstantMean())
+ctx = Context(0)
+p = Problem(ctx, X, Y, spec, max_batch=3)
+U = spec.unconstrain()[None, :] + 0.2 * rng.normal(size=(3, spec.n_trainable))
+cols = np.arange(3, dtype=np.int32)
+f, g, st = p.value_grad(cols, U)
+th = spec.constrain(U[0])
+np.savez(sys.argv[2], f=f, g=g, st=st, M=p.dbg_stage(0, th, 1), Kinv=p.dbg_stage(0, th, 2), X=X, Y=Y, U=U)
+"""
+
+
+def test_every_tile_regime_gives_the_same_bits(tmp_path):
+    """The products of the recursion run on 128 x 128 tiles (full batches; the kernels that skip the all-zero fragments
+    of triangular operands and launch diagonal tiles separately) or on the small 64 x 64 tile (few fits in flight),
+    chosen by launch size.  The choice is read once per process, so two child processes evaluate the same fits with
+    the default choice (small tiles here) and with 128-wide tiles forced everywhere: same bits, and the oracle's
+    numbers."""
+    import subprocess
+    import sys
+
+    root = str(Path(__file__).resolve().parents[1])
+    script = tmp_path / "regime.py"
+    script.write_text(_TILE_REGIME_SCRIPT)
+    outs = {}
+    for name, extra in (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"})):
+        env = dict(os.environ, **extra)
+        out = tmp_path / f"{name}.npz"
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
+        outs[name] = np.load(out)
+    a, b = outs["default"], outs["wide"]
+    for key in ("f", "g", "M", "Kinv"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert np.all(a["st"] == 0)
+    kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),
+                  K.Product([K.Periodic(K.SquaredExponential(active_dims=[0])), K.Lin(active_dims=[2])])])
+    d = ModelSpec(kern, 3, K.GaussianLikelihood(), K.ConstantMean()).to_dict()
+    for t in range(3):
+        fo, go = o.objective(d, a["U"][t], a["X"], a["Y"][:, t])
+        assert a["f"][t] == pytest.approx(fo, rel=1e-10, abs=1e-10)
+        assert np.max(np.abs(a["g"][t] - go)) <= 1e-7 * max(1.0, np.max(np.abs(go)))
