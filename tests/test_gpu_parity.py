@@ -927,14 +927,16 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
     script = tmp_path / "regime.py"
     script.write_text(_TILE_REGIME_SCRIPT)
     outs = {}
-    for name, extra in (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"})):
+    for name, extra in (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
+                        ("unpaired", {"WV_PAIR": "0"})):  # (trailing update and T as two launches instead of one)
         env = dict(os.environ, **extra)
         out = tmp_path / f"{name}.npz"
         subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
         outs[name] = np.load(out)
-    a, b = outs["default"], outs["wide"]
-    for key in ("f", "g", "M", "Kinv"):
-        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    a = outs["default"]
+    for other in ("wide", "unpaired"):
+        for key in ("f", "g", "M", "Kinv"):
+            np.testing.assert_array_equal(a[key], outs[other][key], err_msg=f"{other}: {key}")
     assert np.all(a["st"] == 0)
     kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),
                   K.Product([K.Periodic(K.SquaredExponential(active_dims=[0])), K.Lin(active_dims=[2])])])
