@@ -20,7 +20,8 @@
 // pairs every row group with every column group, so 4 A fragments x (4 column sets x 4
 // rotations) = 64 MFMAs fill a 64 x 64 wave tile per k-step of 4.
 //
-// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x BN (BN = 128 or 64), K chunk 16.
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x BN (BN = 128 or 64), K chunk 16; launches too small to fill
+// the GPU with those use a 64 x 64 block tile, the four waves side by side (TAG bit 4 of the kernel template).
 // Operand tiles are staged global -> registers -> LDS, double-buffered, one barrier per chunk.
 // LDS images keep the fragment reads (lane l: row l&15 permuted within its 16, k = l>>4)
 // bank-conflict free with ds_read_b64:
