@@ -310,6 +310,28 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
         auto chunk = [&](auto i0c, auto i1c, auto j0c, auto j1c) {
           constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
           constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+          if constexpr (SMALL && !NOLDS) {
+            // small tile: 16 MFMAs per k-step cannot hide the LDS latency of their own 8 fragment reads, and at ~100
+            // VGPRs there is room to fetch the next k-step's fragments while this one's MFMAs run
+            double af[2][4], bq[2][4];
+            auto fetch = [&](int s, int buf) {
+#pragma unroll
+              for (int i = I0; i < I1; ++i) af[buf][i] = a_s[TA::at(i * 16 + fr, s * 4 + fk)];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bq[buf][r] = b_s[TB::at(wn * WCOLS + brot[r], s * 4 + fk)];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < KC / 4; ++s) {
+              if (s + 1 < KC / 4) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = I0; i < I1; ++i)
+                  acc[i][0][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[s & 1][i], bq[s & 1][r], acc[i][0][r], 0, 0, 0);
+            }
+            return;
+          }
 #pragma unroll OCC == 1 ? 4 : 1
           for (int s = 0; s < KC / 4; ++s) {
             double af[4];
