@@ -334,3 +334,36 @@ def test_replace_kernel_variables_and_randomize_params():
     np.random.seed(3)
     u = np.random.normal(size=m._spec().n_trainable)
     np.testing.assert_allclose(m._spec().unconstrain(), u, rtol=1e-9, atol=1e-9)
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """The Python binding restates the header's structs by hand: compile a C program against include/waveome_amd.h
+    that prints every struct's size and field offsets and compare with the ctypes classes."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    from waveome_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = Path(__file__).resolve().parents[1]
+    pairs = {"wv_factor": _lib.Factor, "wv_param": _lib.Param, "wv_kernel_spec": _lib.KernelSpec,
+             "wv_problem_caps": _lib.ProblemCaps, "wv_lbfgs_opts": _lib.LbfgsOpts}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root / "include" / "waveome_amd.h"}"',
+             'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
