@@ -287,6 +287,75 @@ def test_fit_reproduces_reference_known_answers(ctx, golden_dir):
         prob.close()
 
 
+def test_kat5_periodic_known_answer_through_gpu(ctx, golden_dir):
+    """KAT-5: the reference's stored Periodic answer ('# Per = -12.242', gpflow_basic_colab.ipynb cells 4, 7) - the
+    headline structure's second factor - through the GPU fit from the GPflow defaults, as the notebook ran it."""
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    with open(os.path.join(golden_dir, "kat.json")) as fh:
+        c = json.load(fh)["kat5"]
+    X = np.array(c["X"]).reshape(-1, 1)
+    Y = np.array(c["Y"]).reshape(-1, 1)
+    ms = ModelSpec(K.Periodic(K.SquaredExponential()), 1, mean_function=None)
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    res = prob.fit([0], ms.unconstrain()[None, :], lbfgs_opts(maxiter=100))
+    assert abs(res["lml"][0] - c["expected"]["lml_3dp"]) < 1e-3          # the notebook's printed digits
+    assert res["lml"][0] == pytest.approx(c["oracle_record"]["lml"], abs=2e-5)  # the oracle's end of the same path
+    th = ms.constrain(res["u"][0])
+    np.testing.assert_allclose(th[:3], c["oracle_record"]["theta"][:3], rtol=2e-3)
+    # value and gradient at the oracle's end point (noise at its 1e-6 floor: K_y is as ill-conditioned as it gets)
+    d = ms.to_dict()
+    u_ref = o.pack_u(d, np.array(c["oracle_record"]["theta"]))
+    f_ref, g_ref = o.objective(d, u_ref, X, Y[:, 0])
+    f, g, st = prob.value_grad([0], u_ref[None, :])
+    assert st[0] == 0 and f[0] == pytest.approx(f_ref, rel=1e-9)
+    np.testing.assert_allclose(g[0], g_ref, rtol=1e-5, atol=1e-7)
+    prob.close()
+
+
+def test_fit_trajectory_first_iterations_n2048(ctx):
+    """Fit-level parity at the headline size: SciPy L-BFGS-B on the oracle objective (what
+    waveome/model_classes.py:325-334 runs) and the device fit take the same first 10 iterations on a bench column -
+    same loss after every iteration (1e-9 relative), same number of evaluations.  (The whole 100-iteration
+    trajectories of three bench columns are compared by tools/fit_trajectory_parity.py,
+    profiles/r03_fit_trajectory_parity.txt.)"""
+    import scipy.optimize
+
+    import bench
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = bench.make_inputs(4)
+    ms = bench.headline_spec()
+    d = ms.to_dict()
+    col, iters = 1, 10
+    u0 = ms.unconstrain()
+    seen, losses = {}, []
+
+    def fun(u):
+        f, g = o.objective(d, u, X, Y[col])
+        seen[tuple(u)] = f
+        return f, g
+
+    ref = scipy.optimize.minimize(fun, u0, jac=True, method="L-BFGS-B", callback=lambda xk: losses.append(seen[tuple(xk)]),
+                                  options=dict(maxiter=iters, maxfun=100000, ftol=0.0, gtol=0.0))
+    assert ref.nit == iters and len(losses) == iters
+    prob = Problem(ctx, X, Y.T, ms, max_batch=iters)
+    # iterate k of the device fit = the fit re-run with maxiter = k (deterministic); all ten in one batch
+    for k in range(1, iters + 1):
+        r = prob.fit([col], u0[None, :], lbfgs_opts(maxiter=k, maxfun=100000, ftol=0.0, gtol=0.0))
+        assert r["nit"][0] == k and r["status"][0] == _lib_codes().LB_STOP_MAXITER
+        assert r["loss"][0] == pytest.approx(losses[k - 1], rel=1e-9), k
+    assert r["nfev"][0] == ref.nfev
+    np.testing.assert_allclose(r["u"][0], ref.x, rtol=0, atol=1e-6)
+    prob.close()
+
+
+def _lib_codes():
+    from waveome_amd import _lib
+
+    return _lib
+
+
 def test_batched_fit_matches_scipy_oracle(ctx):
     """Many tasks through the work queue (more tasks than slots), against SciPy L-BFGS-B on the
     oracle objective. LML at the optimum to 1e-8 rel, hyper-parameters to 1e-4 rel."""

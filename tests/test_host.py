@@ -119,17 +119,28 @@ def test_lbfgs_on_reference_known_answers(lib, golden_dir):
     import json
 
     kat = json.load(open(os.path.join(golden_dir, "kat.json")))
-    for name in ("kat1", "kat2", "kat3"):
+    for name in ("kat1", "kat2", "kat5", "kat3"):
         c = kat[name]
         X, Y = np.array(c["X"]).reshape(-1, 1), np.array(c["Y"])
         spec = o.make_spec(1, [[(c["kernel"], [0])]], mean=False)
         fun = lambda u: o.objective(spec, u, X, Y)
         u0 = o.pack_u(spec, o.theta_init(spec))
-        res, _ = _run_scipy(fun, u0, maxiter=100)
+        res, _ev = _run_scipy(fun, u0, maxiter=100)
         mine = _run_mine(lib, fun, u0, maxiter=100)
+        if name == "kat5":
+            # the reference's stored Periodic answer, printed to 3 decimals. This 83-evaluation path ends in a flat
+            # valley (noise -> its 1e-6 floor) and is chaotic in the last bits: the two-loop recursion here and
+            # SciPy's compact form agree to 1e-10 in every trial point for 50 evaluations, 1e-5 after 60, and stop
+            # three iterations apart, 6e-7 nats from each other - both on the notebook's number
+            assert abs(-mine["f"] - c["expected"]["lml_3dp"]) < 1e-3 and abs(-res.fun - c["expected"]["lml_3dp"]) < 1e-3
+            assert mine["f"] == pytest.approx(res.fun, abs=5e-6)
+            assert abs(mine["nit"] - res.nit) <= 6 and abs(mine["nfev"] - res.nfev) <= 6
+            for (xa, fa), (xb, fb) in list(zip(mine["evals"], _ev))[:50]:
+                np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-7)
+            continue
         assert (mine["nit"], mine["nfev"]) == (res.nit, res.nfev)
         assert mine["f"] == pytest.approx(res.fun, rel=1e-12)
-    # KAT-1's stored LML
+    # KAT-3's optimum (stored as -10.68)
     assert -mine["f"] == pytest.approx(-10.689592369875864, rel=1e-10)
 
 
@@ -367,3 +378,19 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_deviance_explained_rows_with_zero_null_deviance():
+    """waveome/utilities.py:591-607: row by row, a row whose null deviance is 0 (y equals the base mean) gets
+    ratio 1, i.e. explains 0 - not 1; the aggregate is 1 - sum / sum (0 when the null deviance vanishes)."""
+    from waveome_amd.utilities import calc_deviance_explained
+
+    y = np.array([0.0, 1.0, 2.0, 1.0])          # mean 1: rows 1 and 3 have null deviance 0
+    mu = np.array([0.1, 1.3, 1.8, 1.0])
+    rows = calc_deviance_explained(None, data=(None, y), model_mu=mu, aggregate=False)
+    np.testing.assert_allclose(rows, [1 - 0.01 / 1.0, 0.0, 1 - 0.04 / 1.0, 0.0], atol=1e-12)
+    agg = calc_deviance_explained(None, data=(None, y), model_mu=mu, aggregate=True)
+    assert agg == pytest.approx(1 - (0.01 + 0.09 + 0.04) / 2.0)
+    null_dev, model_dev = calc_deviance_explained(None, data=(None, y), model_mu=mu, aggregate=False,
+                                                  return_deviance_explained=False)
+    np.testing.assert_allclose(null_dev * np.var(y), [1, 0, 1, 0], atol=1e-12)

@@ -177,9 +177,11 @@ def calc_deviance_explained(model, data=None, model_mu=None, model_var=None, bas
         null_dev, model_dev = float(np.sum(null_dev)), float(np.sum(model_dev))
         explained = 1 - model_dev / null_dev if null_dev > 0 else 0
     else:
-        explained = np.ones_like(model_dev, dtype=float)
-        np.divide(model_dev, null_dev, out=explained, where=null_dev != 0)
-        explained = 1 - np.where(null_dev != 0, explained, 0.0)
+        # rows whose null deviance is 0 (y equals the base mean) explain nothing: ratio 1 there, as in the
+        # reference (utilities.py:600-607)
+        ratio = np.ones_like(model_dev, dtype=float)
+        np.divide(model_dev, null_dev, out=ratio, where=null_dev != 0)
+        explained = 1 - ratio
     return explained if return_deviance_explained else (null_dev, model_dev)
 
 
