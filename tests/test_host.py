@@ -22,17 +22,34 @@ def lib():
     return _lib.load()
 
 
+def _declared(hdr):
+    text = open(os.path.join(ROOT, "include", hdr)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(wv_[a-z0-9_]+)\s*\(", text))
+
+
 def test_library_exports_every_declared_symbol(lib):
-    declared = set()
-    for hdr in ("waveome_amd.h", "waveome_amd_debug.h"):
-        text = open(os.path.join(ROOT, "include", hdr)).read()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        declared |= set(re.findall(r"\b(wv_[a-z0-9_]+)\s*\(", text))
+    declared = _declared("waveome_amd.h") | _declared("waveome_amd_debug.h")
     assert len(declared) >= 30
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and headers disagree"
     assert lib.wv_abi_version() == 2
+
+
+def test_release_library_carries_no_experiments(lib):
+    """The timing / launch-order experiments of the GEMM kernel (some return wrong numbers on purpose) and the rate
+    probes exist only in the `make probes` build: the release library exports none of the probe symbols and does not
+    even contain the names of the environment switches."""
+    probes = _declared("waveome_amd_probes.h")
+    assert probes == set(_lib.PROBE_SIGNATURES) and len(probes) >= 5
+    if os.environ.get("WAVEOME_AMD_LIB"):
+        pytest.skip("a diagnostic build is loaded")
+    for name in sorted(probes):
+        assert not hasattr(lib, name), f"{name} is a probe and must not be in the release library"
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for switch in (b"WV_GEMM_DBG", b"WV_ROT_TRI", b"WV_GEMM_OCC", b"WV_GEMM_LATIN"):
+        assert switch not in blob, switch
 
 
 def test_no_gpu_fails_loudly_not_silently(lib):

@@ -8,6 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd import ModelSpec, kernels as K  # noqa: E402
 from waveome_amd.engine import Context, Problem, lbfgs_opts  # noqa: E402
 

@@ -5,6 +5,7 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd import ModelSpec, kernels as K  # noqa: E402
 from waveome_amd.engine import Context, Problem  # noqa: E402
 

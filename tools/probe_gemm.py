@@ -1,4 +1,5 @@
 import sys; sys.path.insert(0,'.')
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 c=Context(0)
 print("mode 0 full, 1 lauum-like (lower tiles, contraction from the tile row), 2 syrk-like (lower tiles, beta = 1), 3 trimmed k < n0 + BN")

@@ -4,6 +4,7 @@ Run once per setting: WV_GEMM_DBG=<bits> python tools/probe_gemm_parts.py"""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 c = Context(0)
 print("WV_GEMM_DBG =", os.environ.get("WV_GEMM_DBG", "0"))

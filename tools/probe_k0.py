@@ -3,6 +3,7 @@ M = N = 2048, 64 matrices, for a range of K - the rate follows peak * K / (K + K
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 ctx = Context(0)
 for beta_mode, name in [(0, "beta=0"), (5, "beta=1")]:

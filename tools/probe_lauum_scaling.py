@@ -2,6 +2,7 @@
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 ctx = Context(0)
 for N, nb in [(1024, 1024), (2048, 256), (4096, 64), (8192, 16), (16384, 4)]:

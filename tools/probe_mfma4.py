@@ -1,5 +1,6 @@
 import sys; sys.path.insert(0,'.')
 import numpy as np, ctypes as C
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 from waveome_amd import _lib
 c=Context(0)

@@ -1,4 +1,5 @@
 import sys; sys.path.insert(0,'.')
+import _probes_lib  # noqa: F401  (diagnostic build: tools/libwv_probes.so)
 from waveome_amd.engine import Context
 c=Context(0)
 for wps in (1,2,4):

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (WAVEOME_AMD_LIB: a diagnostic build of the same sources, e.g. tools/libwv_stamps.so)
+# (WAVEOME_AMD_LIB: a diagnostic build of the same sources - tools/libwv_stamps.so, tools/libwv_probes.so)
 LIB_PATH = os.environ.get("WAVEOME_AMD_LIB") or os.path.join(_HERE, "libwaveome_amd.so")
 
 WV_OK = 0
@@ -113,9 +113,14 @@ SIGNATURES = {
     # include/waveome_amd_debug.h
     "wv_dbg_gemm": (C.c_int32, [_vp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32]),
-    "wv_dbg_gemm_bench": (C.c_int32, [_vp] + [C.c_int32] * 8 + [_dp, _dp]),
     "wv_dbg_stage": (C.c_int32, [_vp, C.c_int32, _dp, C.c_int32, _dp]),
     "wv_dbg_npad": (C.c_int64, [_vp]),
+}
+
+# include/waveome_amd_probes.h: rate / timing probes, present only in the `make probes` build
+# (tools/libwv_probes.so through WAVEOME_AMD_LIB); bound when the loaded library exports them
+PROBE_SIGNATURES = {
+    "wv_dbg_gemm_bench": (C.c_int32, [_vp] + [C.c_int32] * 8 + [_dp, _dp]),
     "wv_dbg_mfma_f64_rate": (C.c_int32, [_vp, C.c_int32, C.c_int32, _dp, _dp]),
     "wv_dbg_valu_f64_rate": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "wv_dbg_mfma4_probe": (C.c_int32, [_vp, _ip]),
@@ -143,6 +148,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in PROBE_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.wv_abi_version() != 2:
         raise WaveomeAmdError("libwaveome_amd.so ABI version mismatch")
     _lib = lib

@@ -84,9 +84,11 @@ struct GemmArgsT {
   int32_t ldct, tout;
   int32_t tag;         // 1: launch the separately named instantiation (K_y^-1 = M'M)
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
-  int32_t latin;
+#ifdef WV_EXPERIMENTS   // `make probes` only (wv_gemm.hip): the release kernels have no switch that can change a result
+  int32_t latin;       // 0: per-matrix rotation of the launch order, 1: Latin-square skew (release behaviour), 2: both
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
-  int32_t prio;        // timing-experiment switches (WV_GEMM_DBG; 0 in production)
+  int32_t xskip;       // WV_GEMM_DBG: parts of the kernel switched off for timing (results become wrong)
+#endif
   // Block structure (wv_spec.hpp, block_column): when `spans` is set, a matrix whose structure (slot_spec -> spec_span)
   // has a span table only walks the k that can meet a non-zero in both operands: with (sp_r0, sp_c0, sp_k0) the
   // K_y-index of the product's row 0, column 0 and k = 0, a tile's range is cut to span(rows) ^ span(columns).

@@ -36,6 +36,16 @@
 
 namespace wv {
 
+// Timing / scheduling experiments (switching parts of the kernel off - results become WRONG -, alternative launch
+// orders, one workgroup per CU) exist only in the `make probes` build (-DWV_EXPERIMENTS, tools/libwv_probes.so,
+// loaded through WAVEOME_AMD_LIB by tools/probe_gemm_parts.py).  The release library has no such code path: WV_X(bit)
+// is the constant false and the GemmArgs fields the switches live in do not exist.
+#ifdef WV_EXPERIMENTS
+#define WV_X(bit) ((g.xskip & (bit)) != 0)
+#else
+#define WV_X(bit) false
+#endif
+
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128;
@@ -130,7 +140,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   constexpr int WCOLS = SMALL ? BN / 4 : BN / 2;  // columns of a wave's sub-tile (its rows: 64)
   using TA = Tile<BM, A_KC>;
   using TB = Tile<BN, B_KC>;
+#ifdef WV_EXPERIMENTS
   constexpr bool NOLDS = (TAG & 8) != 0;  // timing experiment only: fragments are constants, no LDS reads in the K loop
+#else
+  constexpr bool NOLDS = false;
+#endif
   constexpr int NJ = WCOLS / 16;  // B fragments per wave
   // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
   // image of half the C tile in the epilogue
@@ -159,13 +173,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   // When the contraction length depends on the tile COLUMN it repeats with period tiles_n in launch
   // order; workgroups appear to be dealt to an XCD's shader engines in order, round-robin, so a
   // power-of-two period leaves some engines with only short tiles and the in-order dealer stalls on
-  // the full ones (PMC: 1.3 instead of 2 resident waves per SIMD).  Default fix: the Latin-square skew
-  // below (latin = 1); latin = 0 is the older per-matrix rotation of the launch order.
+  // the full ones (PMC: 1.3 instead of 2 resident waves per SIMD).  The fix is the Latin-square skew below; the
+  // older per-matrix rotation of the launch order survives in the probes build only (WV_GEMM_LATIN=0 / 2).
+#ifdef WV_EXPERIMENTS
+  const bool latin = g.latin != 0;
   if ((g.khi_mode == 2 || g.klo_mode == 2) && !g.tri && g.latin != 1) tile = (tile + 3 * (b >> 3) + (b & 7)) % tiles;
+#else
+  constexpr bool latin = true;
+#endif
   int tm, tn;
   if (g.tri) {
+#ifdef WV_EXPERIMENTS
     // (rotating lower-only products or row-dependent lengths the same way measured no gain)
     if (g.rot_tri > 0) tile = (tile + ((5 * (b >> 3) + (b & 7)) & 31)) % tiles;
+#endif
     if (g.tri == 2) {  // the diagonal tiles only (square tiles, tri_off == 0)
       tm = tile;
       tn = tile;
@@ -185,7 +206,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
     tn = tile % g.tiles_n;
     // column-dependent lengths: skew every tile row by its index (Latin square) so that any
     // power-of-two stride through the launch order meets every length equally often
-    if (g.latin && (g.khi_mode == 2 || g.klo_mode == 2)) tn = (tn + tm) % g.tiles_n;
+    if (latin && (g.khi_mode == 2 || g.klo_mode == 2)) tn = (tn + tm) % g.tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -286,7 +307,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nchunk && !(g.prio & 4)) {
+    if (c + 1 < nchunk && !WV_X(4)) {
       const int kn = kb + (c + 1) * kstep;
       TA::gload(ra, TA::chunk_base(A, g.lda, m0, kn), offa);
       TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
@@ -294,7 +315,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
-    if (kc0 >= wkb && kc0 < wke && !(g.prio & 8)) {
+    if (kc0 >= wkb && kc0 < wke && !WV_X(8)) {
       if constexpr (TRIOPT) {
         if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
         else mma_chunk_diag<true, TA, TB, NJ>(acc, a_s, b_s, wm * 64, wn * WCOLS, brot, fr, fk);
@@ -389,7 +410,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
       TA::sstore(sA[cur ^ 1], ra, tid);
       TB::sstore(sB[cur ^ 1], rb, tid);
     }
-    if (!(g.prio & 16)) __syncthreads();
+    if (!WV_X(16)) __syncthreads();
   }
 
   // ---- epilogue: C = beta*C + alpha*acc.  D lane 16 i' + 4 blk + j of accumulator (i, j, r)
@@ -399,7 +420,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   // D lane 16 i' + 4 blk + jj of accumulator (i, j, r) is row 16 i + 4 blk + i', column
   // 16 j + 4((blk + r) & 3) + jj of the wave tile. ----
   const double alpha = g.alpha, beta = g.beta;
-  if (g.prio & 2) {  // (timing experiment) keep the accumulators alive with one store
+  if (WV_X(2)) {  // (timing experiment) keep the accumulators alive with one store
     double sink = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -449,7 +470,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
           v.x += beta * cv[it].x;
           v.y += beta * cv[it].y;
         }
-        if (TOUT != 1 && (!(g.prio & 1) || v.x == 1.2345e-300)) *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
+        if (TOUT != 1 && (!WV_X(1) || v.x == 1.2345e-300)) *reinterpret_cast<d2*>(C + (int64_t)m * g.ldc + n) = v;
       }
     }
     if (TOUT != 0) {
@@ -504,24 +525,27 @@ static int prepare_gemm(GemmArgs& a, int BM, int bn) {
     for (int tm = 0; tm < a.tiles_m; ++tm)
       tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / bn + 1));
   }
+  a.tiles_live = tiles;
+#ifdef WV_EXPERIMENTS
   {
     static int lat = -1;
     if (lat < 0) { const char* e = getenv("WV_GEMM_LATIN"); lat = e ? atoi(e) : 1; }
-    a.latin = lat;  // 0: per-matrix rotation, 1: Latin-square skew only, 2: both
+    a.latin = lat;  // 0: per-matrix rotation, 1: Latin-square skew only (what the release build does), 2: both
   }
-  a.tiles_live = tiles;
   {
     // timing experiments only (results become wrong): 1 = no global C stores, 2 = no epilogue at all,
-    // 4 = no global operand loads inside the K loop, 8 = no MFMAs, 16 = no barrier in the K loop
+    // 4 = no global operand loads inside the K loop, 8 = no MFMAs, 16 = no barrier in the K loop,
+    // 32 = full K-strided products on the no-LDS-reads instantiation
     static int dg = -1;
     if (dg < 0) { const char* e = getenv("WV_GEMM_DBG"); dg = e ? atoi(e) : 0; }
-    a.prio = dg;
+    a.xskip = dg;
   }
   {
     static int rt = -1;
     if (rt < 0) { const char* e = getenv("WV_ROT_TRI"); rt = e ? atoi(e) : 0; }
     a.rot_tri = rt;
   }
+#endif
   if (tiles <= 0) return 0;
   return (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
 }
@@ -564,15 +588,17 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
   if (grid <= 0) return;
   const int tiles = a.tiles_live;
   dim3 g(grid), blk(256);
+#ifdef WV_EXPERIMENTS
   static int occ = -1;
   if (occ < 0) {
     const char* e = getenv("WV_GEMM_OCC");
     occ = (e && atoi(e) == 1) ? 1 : 2;
   }
-  if ((a.prio & 32) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // (timing experiment)
+  if ((a.xskip & 32) && !a_kc && !b_kc && bn == 128 && a.tout == 0) {  // (timing experiment)
     hipLaunchKernelGGL((gemm_f64_kernel<false, false, 128, 2, 0, 8>), g, blk, 0, st, a);
     return;
   }
+#endif
   if (small) {  // the three operand layouts of the recursion (S, trailing update / T / M'M, M21) and the NT form
     if (a.tout == 1 && a_kc && !b_kc) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 64, 2, 1, 16>), g, blk, 0, st, a);
     else if (a.tout == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 64, 2, 2, 16>), g, blk, 0, st, a);
@@ -622,11 +648,15 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     }
     return;
   }
+#ifdef WV_EXPERIMENTS
 #define WV_LAUNCH(AK, BK, BNN)                                                  \
   do {                                                                          \
     if (occ == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 1, 0>), g, blk, 0, st, a); \
     else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 2, 0>), g, blk, 0, st, a);          \
   } while (0)
+#else
+#define WV_LAUNCH(AK, BK, BNN) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, BNN, 2, 0>), g, blk, 0, st, a)
+#endif
   if (bn == 128) {
     if (a_kc && b_kc) WV_LAUNCH(true, true, 128);
     else if (a_kc && !b_kc) WV_LAUNCH(true, false, 128);

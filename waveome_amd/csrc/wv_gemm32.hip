@@ -265,8 +265,6 @@ void launch_gemm(hipStream_t st, const GemmArgsF& a_in, bool a_kc, bool b_kc, in
       tiles += std::min(a.tiles_n, std::max(0, (tm * BM + BM - 1 - a.tri_off) / BN + 1));
   }
   a.tiles_live = tiles;
-  a.latin = 1;
-  a.rot_tri = 0;
   if (tiles <= 0) return;
   const int grid = (a.nbatch >= 8) ? 8 * ((a.nbatch + 7) / 8) * tiles : a.nbatch * tiles;
   dim3 g(grid), blk(256);

@@ -51,30 +51,39 @@ class Context:
     def synchronize(self):
         _lib.check(self.lib.wv_ctx_synchronize(self.handle), "wv_ctx_synchronize")
 
-    # ---- bring-up probes (include/waveome_amd_debug.h) ----
+    # ---- rate probes (include/waveome_amd_probes.h): only in the `make probes` build, not in the release library ----
+    def _probe(self, name):
+        fn = getattr(self.lib, name, None)
+        if fn is None:
+            raise _lib.WaveomeAmdError(
+                f"{name} is a probe of the diagnostic build: `make -C waveome_amd/csrc probes`, then run with "
+                "WAVEOME_AMD_LIB=tools/libwv_probes.so (tools/_probes_lib.py does the latter)")
+        return fn
+
     def mfma_f64_rate(self, iters=20000, waves_per_simd=1):
         tf, ms = C.c_double(), C.c_double()
-        _lib.check(self.lib.wv_dbg_mfma_f64_rate(self.handle, iters, waves_per_simd, C.byref(tf),
+        _lib.check(self._probe("wv_dbg_mfma_f64_rate")(self.handle, iters, waves_per_simd, C.byref(tf),
                                                  C.byref(ms)), "wv_dbg_mfma_f64_rate")
         return tf.value, ms.value
 
     def valu_f64_rate(self, iters=20000, waves_per_simd=2, mode=0):
         v, m = C.c_double(), C.c_double()
-        _lib.check(self.lib.wv_dbg_valu_f64_rate(self.handle, iters, waves_per_simd, mode, C.byref(v),
+        _lib.check(self._probe("wv_dbg_valu_f64_rate")(self.handle, iters, waves_per_simd, mode, C.byref(v),
                                                  C.byref(m)), "wv_dbg_valu_f64_rate")
         return v.value, m.value
 
     def gemm_bench(self, M, N, K, a_kcontig=True, b_kcontig=True, bn=128, nbatch=1, iters=5):
         tf, ms = C.c_double(), C.c_double()
-        _lib.check(self.lib.wv_dbg_gemm_bench(self.handle, M, N, K, int(a_kcontig), int(b_kcontig), bn,
+        _lib.check(self._probe("wv_dbg_gemm_bench")(self.handle, M, N, K, int(a_kcontig), int(b_kcontig), bn,
                                               nbatch, iters, C.byref(tf), C.byref(ms)), "wv_dbg_gemm_bench")
         return tf.value, ms.value
 
     def copy_rate(self, nbytes=1 << 30, iters=10):
         g = C.c_double()
-        _lib.check(self.lib.wv_dbg_copy_rate(self.handle, int(nbytes), iters, C.byref(g)), "wv_dbg_copy_rate")
+        _lib.check(self._probe("wv_dbg_copy_rate")(self.handle, int(nbytes), iters, C.byref(g)), "wv_dbg_copy_rate")
         return g.value
 
+    # ---- test hooks of the release library (include/waveome_amd_debug.h) ----
     def dbg_gemm(self, A, B, Cm, a_kcontig=True, b_kcontig=True, bn=128, alpha=1.0, beta=0.0):
         """A: [nb, M, K] (or [nb, K, M] if not a_kcontig); B likewise; Cm: [nb, M, N] updated copy."""
         A = np.ascontiguousarray(A, dtype=np.float64)
