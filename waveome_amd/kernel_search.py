@@ -75,85 +75,160 @@ def _freeze_variance(k):
         K.set_trainable(k.base_kernel.variance, False)
 
 
+class _Form:
+    """A model structure the way the search manipulates it: an ordered list of additive terms, each an ordered list of
+    (label, kernel) factors, label = `kernel_info` of the factor.  Candidate names and kernels are both RENDERED from
+    this one form (`name`, `kernel()`), so they cannot drift apart.  The rules of one search step
+    (model_search.py:2347-2664) are the three methods below; where a term or factor is placed is part of the
+    reference's naming contract (names are compared as whole strings, terms are only ever prepended, appended or moved
+    once - not sorted)."""
+
+    def __init__(self, terms):
+        self.terms = [list(t) for t in terms]
+
+    @classmethod
+    def parse(cls, kernel, name):
+        comps = list(kernel.kernels) if kernel.name == "sum" else [kernel]
+        terms = []
+        for part, comp in zip(name.split("+"), comps):
+            factors = list(comp.kernels) if comp.name == "product" else [comp]
+            terms.append(list(zip(part.split("*"), factors)))
+        return cls(terms)
+
+    @staticmethod
+    def _term_name(term):
+        return "*".join(label for label, _ in term)
+
+    @property
+    def name(self):
+        return "+".join(self._term_name(t) for t in self.terms)
+
+    def kernel(self):
+        comps = [K.Product([k for _, k in t]) if len(t) > 1 else t[0][1] for t in self.terms]
+        return K.Sum(comps) if len(comps) > 1 else comps[0]
+
+    def mentions_categorical(self, column, term=None):
+        tag = "categorical[" + str(column) + "]"
+        terms = self.terms if term is None else [self.terms[term]]
+        return any(tag in label for t in terms for label, _ in t)
+
+    # -- rule 1: add a term.  The new term goes behind the whole structure if the structure's name sorts before the
+    #    new label, else in front of it.
+    def plus(self, label, kernel):
+        new = [(label, kernel)]
+        return _Form(self.terms + [new] if self.name < label else [new] + self.terms)
+
+    # -- rule 2: multiply term i by a factor.  Two-way interactions only; inside the product the factor whose label
+    #    sorts first leads.  If the existing factor leads the product stays where the term was; if the new factor
+    #    leads the product moves (see below).
+    def times(self, i, label, kernel):
+        term = self.terms[i]
+        if len(term) != 1:
+            return None
+        if self._term_name(term) < label:
+            terms = list(self.terms)
+            terms[i] = term + [(label, kernel)]
+            return _Form(terms)
+        # the new factor leads: the position is looked up among ALL current term names (the old one included), then
+        # the old term is removed and the product inserted at that index of the shortened list; "no later name" means
+        # the last index of the original list
+        names = [self._term_name(t) for t in self.terms]
+        pos = next((j for j, n in enumerate(names) if label < n), len(names) - 1)
+        terms = [t for j, t in enumerate(self.terms) if j != i]
+        terms.insert(pos, [(label, kernel)] + term)
+        return _Form(terms)
+
+    def copy(self, reset=True):
+        """Deep copy; with `reset` every trainable parameter restarts from 1.0 (model_search.py:2420-2421)."""
+        out = _Form([[(label, copy.deepcopy(k)) for label, k in t] for t in self.terms])
+        if reset:
+            for t in out.terms:
+                for _, k in t:
+                    _reset_trainable(k)
+        return out
+
+
+def _structure_key(name: str):
+    """What makes two names the same model for `check_if_model_exists`: the set of additive components, each as its
+    sorted characters (utilities.py:281-307)."""
+    return frozenset("".join(sorted(part)) for part in name.split("+"))
+
+
+class _Seen:
+    """Names of the models fitted so far, looked up by structure."""
+
+    def __init__(self, names: Iterable[str] = ()):
+        self.keys = {_structure_key(n) for n in (names or ())}
+
+    def __contains__(self, name):
+        return _structure_key(name) in self.keys
+
+
+def _proposals(n_features, kern_list, cat_vars, depth):
+    """(column, label, fresh kernel) of every base kernel a step may bring in, feature by feature: the kernel list on a
+    numeric column, Categorical on a categorical one, and once - with the first column at depth 1 - the frozen
+    near-zero constant that stands for "no structure" (model_search.py:2337-2344, 2388-2400)."""
+    for f in range(n_features):
+        fresh = set_feature_kernels(f, [copy.deepcopy(x) for x in kern_list], cat_vars)
+        if f == 0 and depth == 1:
+            nothing = K.Constant(variance=1e-6)
+            K.set_trainable(nothing.variance, False)
+            fresh = fresh + [nothing]
+        for k in fresh:
+            yield f, kernel_info(k), k
+
+
 def prod_kernel_candidates(base_kernel, base_name: str, new_kernel, prev_models: Iterable[str]) -> Dict[str, object]:
-    """Multiply each additive component of `base_kernel` by `new_kernel` (model_search.py:2561-2664)."""
+    """Multiply each additive component of `base_kernel` by `new_kernel` (model_search.py:2561-2664): rule 2 applied
+    to every term that is not yet a product and does not already carry the Categorical kernel of the new column."""
+    seen = prev_models if isinstance(prev_models, _Seen) else _Seen(prev_models)
+    base = _Form.parse(base_kernel, base_name)
+    label, column = kernel_info(new_kernel), new_kernel.active_dims[0]
     out = {}
-    new_info = kernel_info(new_kernel)
-    for feat in range(len(base_kernel.kernels)):
-        temp_kernel = copy.deepcopy(base_kernel)
-        temp_name = base_name.split("+")
-        if "categorical[" + str(new_kernel.active_dims[0]) + "]" in temp_name[feat]:
+    for i in range(len(base.terms)):
+        if base.mentions_categorical(column, term=i):
             continue
-        if "*" in temp_name[feat]:  # two-way interactions only
+        form = base.copy(reset=False).times(i, label, copy.deepcopy(new_kernel))
+        if form is None or form.name in seen:
             continue
-        kerns = list(temp_kernel.kernels)
-        if temp_name[feat] < new_info:
-            temp_name[feat] = temp_name[feat] + "*" + new_info
-            kerns[feat] = K.Product([kerns[feat], copy.deepcopy(new_kernel)])
-        else:
-            prod = K.Product([copy.deepcopy(new_kernel), kerns[feat]])
-            try:
-                new_idx = [new_info < x for x in temp_name].index(True)
-            except ValueError:
-                new_idx = len(temp_name) - 1
-            cur = temp_name.pop(feat)
-            kerns.pop(feat)
-            temp_name.insert(new_idx, new_info + "*" + cur)
-            kerns.insert(new_idx, prod)
-        k_info = "+".join(temp_name)
-        if check_if_model_exists(k_info, list(prev_models)):
-            continue
-        out[k_info] = K.Sum(kerns) if len(kerns) > 1 else kerns[0]
+        out[form.name] = form.kernel()
     return out
 
 
 def loc_kernel_candidates(n_features: int, kern_list: Sequence, base_kern=None, base_name: Optional[str] = None,
                           cat_vars: Sequence[int] = (), depth: int = 0, operation: str = "sum",
                           prev_models: Iterable[str] = ()) -> Dict[str, object]:
-    """Candidates of one local search step: name -> kernel (model_search.py:2347-2558 without the fits)."""
+    """Candidates of one local search step: name -> kernel (model_search.py:2347-2558 without the fits).
+
+    Every proposal (`_proposals`) is combined with the base structure by `operation`:
+      sum            rule 1 (add a term);
+      product        rule 2 on a single base kernel (a product is never multiplied again);
+      split_product  rule 2 on every term of a sum.
+    A column whose Categorical kernel is already in the base brings nothing new (sum / product); a factor that joins
+    a product has its variance frozen at 1 (:2469-2472); structures fitted before are not proposed again."""
+    if operation not in ("sum", "product", "split_product"):
+        raise ValueError(f"unknown operation {operation!r}")
     out: Dict[str, object] = {}
-    prev_models = list(prev_models) if prev_models is not None else []
-    for f in range(n_features):
-        k_list = set_feature_kernels(f, [copy.deepcopy(x) for x in kern_list], cat_vars)
-        if f == 0 and depth == 1:
-            empty_kernel = K.Constant(variance=1e-6)
-            K.set_trainable(empty_kernel.variance, False)
-            k_list = k_list + [empty_kernel]
-        for k in k_list:
-            k_info = kernel_info(k)
-            if base_kern is None:
-                out[k_info] = k
+    if base_kern is None:
+        return {label: k for _, label, k in _proposals(n_features, kern_list, cat_vars, depth)}
+    seen = _Seen(prev_models)
+    base = _Form.parse(base_kern, base_name)
+    for f, label, k in _proposals(n_features, kern_list, cat_vars, depth):
+        if operation == "split_product":
+            _freeze_variance(k)
+            out.update(prod_kernel_candidates(base.copy().kernel(), base_name, k, seen))
+            continue
+        if base.mentions_categorical(f):
+            continue
+        if operation == "sum":
+            form = base.copy().plus(label, k)
+        else:
+            if "*" in base_name:
                 continue
-            base_kern_ = copy.deepcopy(base_kern)
-            _reset_trainable(base_kern_)
-            if operation == "sum":
-                if "categorical[" + str(f) + "]" in base_name:
-                    continue
-                if base_name < k_info:
-                    cand, name = K.Sum([base_kern_, k]), base_name + "+" + k_info
-                else:
-                    cand, name = K.Sum([k, base_kern_]), k_info + "+" + base_name
-                if check_if_model_exists(name, prev_models):
-                    continue
-                out[name] = cand
-            elif operation == "product":
-                if "categorical[" + str(f) + "]" in base_name:
-                    continue
-                if "*" in base_name:
-                    continue
-                _freeze_variance(k)
-                if base_name < k_info:
-                    cand, name = K.Product([base_kern_, k]), base_name + "*" + k_info
-                else:
-                    cand, name = K.Product([k, base_kern_]), k_info + "*" + base_name
-                if check_if_model_exists(name, prev_models):
-                    continue
-                out[name] = cand
-            elif operation == "split_product":
-                _freeze_variance(k)
-                out.update(prod_kernel_candidates(base_kern_, base_name, k, prev_models))
-            else:
-                raise ValueError(f"unknown operation {operation!r}")
+            _freeze_variance(k)
+            form = base.copy().times(0, label, k)
+        if form.name not in seen:
+            out[form.name] = form.kernel()
     return out
 
 
