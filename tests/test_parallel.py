@@ -40,6 +40,24 @@ assert parallel.local_device_index(4, env={"LOCAL_RANK": "6"}) == 2
 mineX = np.full((40, 3), float(rank)); mineY = np.full((40, 11), float(rank))
 sh = parallel.broadcast_inputs(mineX, mineY)      # rank 1's own values must be replaced by rank 0's
 assert sh.X.shape == (40, 3) and sh.Y.shape == (40, 11) and np.all(sh.X == 0.0) and np.all(sh.Y == 0.0)
+# dynamic dealing (parallel.dynamic_map): a task list whose heavy tasks all sit on even indices - the static
+# round-robin deal gives every one of them to rank 0 - is dealt in chunks from the store's counter instead
+import json, time
+cost_ms = np.ones(64); cost_ms[0:32:2] = 25.0
+def work(ids):
+    time.sleep(float(cost_ms[ids].sum()) * 1e-3)
+    return np.column_stack([ids * 2.0 + 0.5, cost_ms[ids]])
+dyn = parallel.dynamic_map(64, parallel.pull_all(work), chunk=2, width=2)
+dyn_stats = parallel.last_map_stats()
+sta = parallel.sharded_map(64, work, width=2)
+sta_stats = parallel.last_map_stats()
+np.save(os.environ["WV_OUT"] + f".dyn{rank}.npy", dyn)
+np.save(os.environ["WV_OUT"] + f".sta{rank}.npy", sta)
+if rank == 0:
+    json.dump({"dynamic": dyn_stats, "static": sta_stats}, open(os.environ["WV_OUT"] + ".stats.json", "w"))
+# fewer chunks than ranks: a rank that draws nothing still joins the gather
+tiny = parallel.dynamic_map(1, parallel.pull_all(work), chunk=4, width=2)
+assert tiny.shape == (1, 2) and tiny[0, 0] == 0.5
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -99,3 +117,33 @@ def test_world_size_two_gloo_matches_single_process(tmp_path):
     np.testing.assert_array_equal(np.load(out + ".one1.npy"), ref[:1])
     i0, i1 = np.load(out + ".ids0.npy"), np.load(out + ".ids1.npy")
     assert sorted(np.concatenate([i0, i1]).tolist()) == list(range(11)) and abs(len(i0) - len(i1)) <= 1
+    # dynamic dealing: same table as one process would compute, on both ranks, and balanced where the static deal is not
+    import json
+
+    ids = np.arange(64)
+    cost_ms = np.ones(64)
+    cost_ms[0:32:2] = 25.0
+    want = np.column_stack([ids * 2.0 + 0.5, cost_ms])
+    for tag in ("dyn", "sta"):
+        np.testing.assert_array_equal(np.load(out + f".{tag}0.npy"), want)
+        np.testing.assert_array_equal(np.load(out + f".{tag}1.npy"), want)
+    stats = json.load(open(out + ".stats.json"))
+    assert stats["dynamic"]["mode"] == "dynamic" and sum(stats["dynamic"]["tasks_per_rank"]) == 64
+    assert stats["dynamic"]["rank_time_max_over_mean"] < 1.15, stats
+    assert stats["static"]["rank_time_max_over_mean"] > 1.5, stats   # (what the skew does to a static split)
+
+
+def test_task_dealer_and_dynamic_map_without_a_process_group():
+    from waveome_amd import parallel
+
+    d = parallel.TaskDealer(10, 4, costs=[1, 9, 1, 1, 9, 1, 1, 1, 1, 5])
+    chunks = [d.pull().tolist() for _ in range(4)]
+    assert chunks == [[1, 4, 9, 0], [2, 3, 5, 6], [7, 8], []] and d.taken == 10   # heaviest first, stable
+    out = parallel.dynamic_map(7, parallel.pull_all(lambda ids: np.column_stack([ids + 0.25, -ids])), chunk=3, width=2)
+    np.testing.assert_array_equal(out, np.column_stack([np.arange(7) + 0.25, -np.arange(7)]))
+    st = parallel.last_map_stats()
+    assert st["mode"] == "dynamic" and st["tasks_per_rank"] == [7] and st["rank_time_max_over_mean"] == 1.0
+    import pytest
+
+    with pytest.raises(RuntimeError):   # a run() that loses tasks it drew is an error, not a silent NaN row
+        parallel.dynamic_map(5, lambda pull: (pull()[:1], np.zeros((1, 1))), chunk=3, width=1)

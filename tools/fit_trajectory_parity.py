@@ -61,6 +61,16 @@ def main():
     st, cnt = np.unique(res["status"], return_counts=True)
     print(f"# GPU: {P} bench columns, maxiter=100, ftol=gtol=0: status counts "
           f"{dict(zip(st.tolist(), cnt.tolist()))}, iterations min {res['nit'].min()} mean {res['nit'].mean():.2f}")
+    table_out = os.environ.get("WV_TABLE_OUT")   # the device fits' end states, column by column (read next to
+    if table_out:                                 # tools/scipy_stop_census.py's table of SciPy's end states)
+        with open(table_out, "w") as fh:
+            fh.write("# device fits of bench.make_inputs(%d), maxiter=100, ftol=gtol=0\n# column nit nfev status final_loss\n" % P)
+            for c in range(P):
+                fh.write(f"{c:8d} {int(res['nit'][c]):4d} {int(res['nfev'][c]):5d} {int(res['status'][c]):6d}  {res['loss'][c]:.10f}\n")
+    if per_status == 0:
+        prob.close()
+        ctx.close()
+        return
     picks = []
     for s in (3, 2, 5):
         idx = np.flatnonzero(res["status"] == s)

@@ -184,6 +184,24 @@ static int wait_group(Problem& p, Group& g) {
   return WV_OK;
 }
 
+// Every C-ABI call that uses the groups' staging buffers or enqueues kernels starts here: a launcher's refusal left
+// over from an earlier call must not fail this one, and while a work queue is open on the problem (wv_queue_*) the
+// staging buffers and slots are the queue's.
+static int enter_device_call(Problem& p, const char* who) {
+  (void)take_launch_failure();
+  if (p.open_queue) {
+    set_error(std::string(who) + ": the problem has an open work queue (wv_queue_*); destroy the queue first");
+    return WV_E_BADARG;
+  }
+  return WV_OK;
+}
+// ... and a launcher that refused a request (fail_launch: message already set) turns WV_OK into WV_E_UNSUPPORTED
+// instead of handing back buffers that were never computed.
+static int leave_device_call(int rc) {
+  const bool refused = take_launch_failure();
+  return (rc == WV_OK && refused) ? WV_E_UNSUPPORTED : rc;
+}
+
 // loss = -(LML + log prior), gradient w.r.t. unconstrained trainables, from a result record
 static void loss_from_record(const Spec& s, const double* u, const double* theta, const double* rec,
                              int status, double* loss, double* grad_u, double* lml_out,
@@ -567,6 +585,7 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  if (int rc = enter_device_call(p, "wv_gram")) return rc;
   Group& g = p.groups[0];
   const int np = p.spec.n_params();
   std::memcpy(g.h_theta, theta, sizeof(double) * np);
@@ -574,6 +593,7 @@ int32_t wv_gram(wv_problem* h, const double* theta, double* K_out) {
                             hipMemcpyHostToDevice, g.stream));
   launch_gram(p, g.stream, g.slot0, 1, 0);
   WV_HIP_TRY(hipGetLastError());
+  if (int rc = leave_device_call(WV_OK)) return rc;
   if (p.f32) {  // float32 storage: fetch as stored, widen on the host
     std::vector<float> tmp((size_t)p.N * p.N);
     WV_HIP_TRY(hipMemcpy2DAsync(tmp.data(), sizeof(float) * p.N, p.Kbuf32 + (int64_t)g.slot0 * p.Npad * p.Npad,
@@ -640,6 +660,7 @@ int32_t wv_lml(wv_problem* h, const int32_t* col_idx, int32_t B, const double* t
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, B);
   if (rc != WV_OK) return rc;
+  if ((rc = enter_device_call(p, "wv_lml")) != WV_OK) return rc;
   std::vector<double> recs;
   std::vector<int32_t> st;
   rc = eval_batch(p, col_idx, B, theta, false, recs, st);
@@ -667,6 +688,7 @@ int32_t wv_value_grad(wv_problem* h, const int32_t* col_idx, int32_t B, const do
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, B);
   if (rc != WV_OK) return rc;
+  if ((rc = enter_device_call(p, "wv_value_grad")) != WV_OK) return rc;
   const int np = p.spec.n_params(), nt = p.spec.n_trainable();
   std::vector<double> theta((size_t)B * np);
   for (int i = 0; i < B; ++i) p.spec.constrain(theta_u + (size_t)i * nt, &theta[(size_t)i * np]);
@@ -757,6 +779,12 @@ int FitQueue::refill_and_launch(int gi) {
   std::vector<Slot> act;
   for (auto& s : sl)
     if (s.live) act.push_back(std::move(s));
+  // fits parked by the drain fold come back first: they already own an optimiser state and, when the queue is fed
+  // incrementally (wv_queue_submit after a fold), must not sit idle until the queue runs dry again
+  while ((int)act.size() < g.nslots && !held_.empty()) {
+    act.push_back(std::move(held_.back()));
+    held_.pop_back();
+  }
   while ((int)act.size() < g.nslots && !queue_.empty()) {
     Slot s;
     s.live = 1;
@@ -784,7 +812,7 @@ int FitQueue::advance() {
   const int np = p_.np_stride;
   // idle groups pick up queued work
   for (int g = 0; g < ng; ++g)
-    if (inflight_[g] == 0 && !queue_.empty()) {
+    if (inflight_[g] == 0 && !queue_.empty()) {  // (refill takes parked fits first, then queued tasks)
       double t2 = now();
       int rc = refill_and_launch(g);
       if (rc != WV_OK) return rc;
@@ -877,6 +905,7 @@ static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* sp
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = check_cols(p, col_idx, n_tasks);
   if (rc != WV_OK) return rc;
+  if ((rc = enter_device_call(p, "wv_fit")) != WV_OK) return rc;
   for (int t = 0; t < n_tasks; ++t) {
     const int si = spec_idx ? spec_idx[t] : 0;
     if (si < 0 || si >= (int)p.specs.size()) {
@@ -1045,7 +1074,9 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
-  int rc = eval_one(p, col, theta);
+  int rc = enter_device_call(p, "wv_predict");
+  if (rc != WV_OK) return rc;
+  rc = eval_one(p, col, theta);
   if (rc != WV_OK) return rc;
   Group& g = p.groups[0];
   if (g.h_status[0] != 0) {
@@ -1120,6 +1151,10 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
       set_error("wv_predict: HIP error in the prediction kernels");
       return WV_E_HIP;
     }
+    if (leave_device_call(WV_OK) != WV_OK) {  // a launcher refused (its message stands): nothing was computed
+      cleanup();
+      return WV_E_UNSUPPORTED;
+    }
     for (int64_t i = 0; i < mc; ++i) {
       if (mean_out) mean_out[m0 + i] = hm[i] + c;
       if (var_out) {
@@ -1153,7 +1188,9 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
-  int rc = eval_one(p, col, theta);  // alpha of the full model
+  int rc = enter_device_call(p, "wv_whitened_means");
+  if (rc != WV_OK) return rc;
+  rc = eval_one(p, col, theta);  // alpha of the full model
   if (rc != WV_OK) return rc;
   Group& g = p.groups[0];
   if (g.h_status[0] != 0) {
@@ -1204,6 +1241,7 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
   const int32_t bad = bad_any;
   WV_HIP_TRY(hipGetLastError());
   (void)K0; (void)q_mu;
+  if (int rc2 = leave_device_call(WV_OK)) return rc2;
   if (bad) {
     set_error("wv_whitened_means: a jittered component Gram matrix was not positive definite");
     return WV_E_BADARG;
@@ -1260,6 +1298,11 @@ int32_t wv_queue_create(wv_problem* h, const wv_lbfgs_opts* opts, wv_queue** out
     set_error("wv_queue_create: null argument");
     return WV_E_BADARG;
   }
+  if (h->p.open_queue) {  // one queue per problem: the groups' staging buffers belong to it
+    set_error("wv_queue_create: the problem already has an open work queue");
+    return WV_E_BADARG;
+  }
+  h->p.open_queue = true;
   auto* w = new wv_queue();
   w->prob = h;
   w->q.reset(new FitQueue(h->p, *opts));
@@ -1324,6 +1367,8 @@ int32_t wv_queue_fetch(wv_queue* w, int32_t cap, int32_t u_stride, int64_t* tags
   while (n < cap && !w->q->done.empty()) {
     const QResult& r = w->q->done.front();
     if ((int)r.u.size() > u_stride) {
+      // the results popped so far stay the caller's (n_out says how many); the wide one stays queued
+      *n_out = n;
       set_error("wv_queue_fetch: u_stride smaller than a fit's number of trainable parameters");
       return WV_E_BADARG;
     }
@@ -1350,6 +1395,7 @@ void wv_queue_destroy(wv_queue* w) {
     for (auto& g : w->prob->p.groups)
       if (g.stream) (void)hipStreamSynchronize(g.stream);
   }
+  if (w->prob) w->prob->p.open_queue = false;
   delete w;
 }
 

@@ -81,6 +81,11 @@ int32_t wv_dbg_stage(wv_problem* h, int32_t col, const double* theta, int32_t wh
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  if (p.open_queue) {
+    set_error("wv_dbg_stage: the problem has an open work queue");
+    return WV_E_BADARG;
+  }
+  (void)take_launch_failure();
   Group& g = p.groups[0];
   hipStream_t st = g.stream;
   const int np = p.spec.n_params();
@@ -118,6 +123,7 @@ int32_t wv_dbg_stage(wv_problem* h, int32_t col, const double* theta, int32_t wh
   if (what == 4) { src = p.dalpha + (int64_t)g.slot0 * p.Npad; bytes = sizeof(double) * p.Npad; }
   WV_HIP_TRY(hipGetLastError());
   WV_HIP_TRY(hipStreamSynchronize(st));
+  if (take_launch_failure()) return WV_E_UNSUPPORTED;
   if (src32) {
     std::vector<float> tmp((size_t)mat);
     WV_HIP_TRY(hipMemcpy(tmp.data(), src32, sizeof(float) * mat, hipMemcpyDeviceToHost));

@@ -192,6 +192,7 @@ struct Problem {
   int64_t workspace_bytes = 0;
   std::vector<Group> groups;
   StageTimer timer;
+  bool open_queue = false;  // a wv_queue owns the groups' staging buffers: every other device entry point is refused
   int64_t pbuf_elems() const { int64_t h = Npad / 2 + NB; return std::max<int64_t>(h * h, Npad * NB); }
   int nblk() const { return (int)(Npad / NB); }
   int ntiles() const { int t = (int)(Npad / GT); return t * (t + 1) / 2; }

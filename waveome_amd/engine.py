@@ -245,6 +245,53 @@ class Problem:
         U[np.arange(U.shape[1])[None, :] >= nts[:, None]] = np.nan
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
 
+    def fit_stream(self, pull, task_args, opts=None, width=None, backlog=None):
+        """Fit a task list that arrives in chunks, keeping the batch full across chunk boundaries: the problem's work
+        queue (wv_queue_*) is topped up from `pull()` whenever fewer than `max_batch + backlog` tasks are queued or in
+        flight.  `pull()` -> array of task ids (empty: nothing left; e.g. parallel.TaskDealer.pull, which deals chunks
+        to the ranks of a job on demand); `task_args(ids)` -> (cols, spec_idx, U0, prior_scale or None) for those ids.
+        Returns (ids, dict of arrays like fit_multi's) in the order the tasks were drawn.  Fits are bit-identical to
+        fit / fit_multi on the same tasks (a slot's arithmetic does not depend on what else is in the batch)."""
+        width = int(width or max(sp.n_trainable for sp in self.specs))
+        backlog = self.max_batch // 4 if backlog is None else int(backlog)
+        q = FitQueue(self, opts, width=width)
+        drawn, got, spec_of = [], {}, {}
+        exhausted = False
+        try:
+            while True:
+                while not exhausted and q.in_system < self.max_batch + max(0, backlog):
+                    ids = np.asarray(pull(), dtype=np.int64)
+                    if len(ids) == 0:
+                        exhausted = True
+                        break
+                    cols, sidx, U0, ps = task_args(ids)
+                    sidx = np.zeros(len(ids), dtype=np.int32) if sidx is None else np.asarray(sidx, dtype=np.int32)
+                    q.submit(cols, sidx, U0, ids, prior_scale=ps)
+                    drawn.append(ids)
+                    spec_of.update(zip(ids.tolist(), sidx.tolist()))
+                if q.in_system == 0 and q.done == 0:
+                    if exhausted:
+                        break
+                    continue
+                done, _ = q.advance()
+                if done:
+                    r = q.fetch(max(done, 64))
+                    for j, tg in enumerate(r["tag"]):
+                        got[int(tg)] = (r["u"][j].copy(), r["loss"][j], r["lml"][j], r["nit"][j], r["nfev"][j],
+                                        r["status"][j])
+        finally:
+            q.close()
+        ids = np.concatenate(drawn) if drawn else np.zeros(0, dtype=np.int64)
+        T = len(ids)
+        out = {"u": np.full((T, width), np.nan), "loss": np.empty(T), "lml": np.empty(T),
+               "nit": np.empty(T, dtype=np.int32), "nfev": np.empty(T, dtype=np.int32),
+               "status": np.empty(T, dtype=np.int32)}
+        for row, t in enumerate(ids):
+            u, out["loss"][row], out["lml"][row], out["nit"][row], out["nfev"][row], out["status"][row] = got[int(t)]
+            nt = self.specs[spec_of[int(t)]].n_trainable
+            out["u"][row, :nt] = u[:nt]   # (NaN past a structure's own parameters, like fit_multi)
+        return ids, out
+
     def predict(self, col, theta, include_noise=True, Xnew=None):
         """Posterior mean / variance (predict_y when include_noise, else predict_f) at the training inputs
         (Xnew=None) or at an (M, D) array of new inputs."""

@@ -500,10 +500,54 @@ class GpuScorer:
                         f.result()
             return rec
 
+        def fit_stream(pull):
+            """This rank's share of a step dealt in chunks (parallel.dynamic_map; candidate fits run to SciPy's
+            tolerances and differ several-fold in cost): one problem holding every structure of the step, one work
+            queue kept full across the chunks drawn.  A task is one candidate: its R restarts travel together."""
+            sig_list = list(groups)
+            sig_pos = {sg: k for k, sg in enumerate(sig_list)}
+            sp_list = [specs[groups[sg][0]] for sg in sig_list]
+            R = self.num_restart
+            mb = self.max_batch or min(-(-len(order) * R // world) + dyn_chunk * R, _default_batch(N))
+            prob = self.shared.problem(self.ctx, sp_list, max(1, mb), nan_is_missing=self.nan_is_missing)
+
+            def pull_fits():  # candidate ids -> fit ids (candidate * R + restart)
+                c = np.asarray(pull(), dtype=np.int64)
+                return (c[:, None] * R + np.arange(R)[None, :]).reshape(-1)
+
+            def task_args(fit_ids):
+                cand = [order[int(f) // R] for f in fit_ids]
+                sidx = np.array([sig_pos[sigs[i]] for i in cand], dtype=np.int32)
+                U0 = np.zeros((len(fit_ids), width))
+                for row, (f, i) in enumerate(zip(fit_ids, cand)):
+                    sp = specs[i]
+                    U0[row, :sp.n_trainable] = (sp.unconstrain() if R == 1 else
+                                                restart_points(sp.n_trainable, R, random_seed=self.random_seed)[int(f) % R])
+                return np.array([tasks[i][0] for i in cand], dtype=np.int32), sidx, U0, None
+
+            try:
+                fit_ids, res = prob.fit_stream(pull_fits, task_args, self.opts, width=width, backlog=mb // 4)
+            finally:
+                prob.close()
+            cand_ids = fit_ids.reshape(-1, R)[:, 0] // R
+            lml = np.where(np.isfinite(res["lml"]), res["lml"], -np.inf).reshape(-1, R)
+            best = np.arange(len(cand_ids)) * R + np.argmax(lml, axis=1)
+            rec = np.full((len(cand_ids), 5 + width), np.nan)
+            rec[:, :5] = np.column_stack([res["loss"][best], res["lml"][best], res["nit"][best], res["nfev"][best],
+                                          res["status"][best]])
+            rec[:, 5:5 + width] = res["u"][best, :width]
+            return cand_ids, rec
+
         if order:
             rank, world = parallel.dist_info()
-            rec = parallel.sharded_map(len(order), fit_shard, costs=costs, width=5 + width) if parallel.dist_active() \
-                else fit_shard(np.arange(len(order)))
+            dyn_chunk = max(1, min(_default_batch(N) // 4, -(-len(order) // (4 * world))))
+            if parallel.dist_active() and self.mode == "multi":
+                rec = parallel.dynamic_map(len(order), fit_stream, dyn_chunk, 5 + width, costs=costs)
+                self.rank_stats = parallel.last_map_stats()
+            elif parallel.dist_active():
+                rec = parallel.sharded_map(len(order), fit_shard, costs=costs, width=5 + width)
+            else:
+                rec = fit_shard(np.arange(len(order)))
             self.n_fits += len(order)
             self.n_structures += len(groups)
             for j, i in enumerate(order):

@@ -5,8 +5,12 @@ Replaces the Ray fan-out of waveome/model_search.py:411-512 (one remote task per
 (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for the CPU tests):
 
   1. rank 0 broadcasts X (N x D) and Y (P x N) once           -> `broadcast_inputs` / `broadcast_array`
-  2. every rank fits a static, cost-balanced shard of tasks    -> `shard_tasks`
+  2. every rank fits its share of the tasks: a static, cost-balanced shard (`shard_tasks` / `sharded_map`: jobs
+     whose tasks cost the same, e.g. the fixed-iteration bench) or chunks dealt on demand from a shared counter
+     (`TaskDealer` / `dynamic_map`: run-to-tolerance jobs, whose fits differ 7x in iterations)
   3. fixed-width result records are all-gathered               -> `gather_records`
+Every map also all-gathers each rank's busy time: `last_map_stats()["rank_time_max_over_mean"]` is the load
+imbalance SURVEY.md 8(e) asks to be reported.
 
 Collectives run on this rank's GPU under nccl (RCCL moves device memory only) and on the CPU under gloo
 (`collective_device`); the GPU of a rank is LOCAL_RANK modulo the visible devices (`local_device_index`).
@@ -208,17 +212,165 @@ def gather_records(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, devic
     return out
 
 
+_LAST_STATS: dict = {}
+
+
+def last_map_stats() -> dict:
+    """What the most recent sharded_map / dynamic_map on this rank measured: {"mode", "rank_seconds" (busy time of
+    every rank between the start of the map and the end of its own work, gather excluded), "tasks_per_rank",
+    "rank_time_max_over_mean"} - the imbalance figure of SURVEY.md 8(e)."""
+    return dict(_LAST_STATS)
+
+
+def _record_stats(mode: str, seconds: float, n_mine: int, device=None) -> dict:
+    rank, world = dist_info()
+    if dist_active():
+        import torch
+
+        dev = collective_device(device)
+        mine = torch.tensor([float(seconds), float(n_mine)], dtype=torch.float64, device=dev)
+        bufs = [torch.empty_like(mine) for _ in range(world)]
+        _dist().all_gather(bufs, mine)
+        tab = np.array([b.cpu().numpy() for b in bufs])
+    else:
+        tab = np.array([[float(seconds), float(n_mine)]])
+    secs = tab[:, 0]
+    _LAST_STATS.clear()
+    _LAST_STATS.update({"mode": mode, "rank_seconds": [float(v) for v in secs],
+                        "tasks_per_rank": [int(v) for v in tab[:, 1]],
+                        "rank_time_max_over_mean": float(secs.max() / secs.mean()) if secs.mean() > 0 else 1.0})
+    return last_map_stats()
+
+
 def sharded_map(n_tasks: int, fn: Callable[[np.ndarray], np.ndarray], costs=None, device=None,
                 width: Optional[int] = None) -> np.ndarray:
-    """Run fn(task_indices) -> [len, width] records on this rank's shard and gather all records.
+    """Run fn(task_indices) -> [len, width] records on this rank's STATIC shard and gather all records.
     With fewer tasks than ranks some shards are empty: pass the record `width` so that those ranks
-    can still take part in the gather."""
+    can still take part in the gather.  Per-rank busy times -> `last_map_stats()`."""
+    import time
+
     rank, world = dist_info()
     ids = shard_tasks(n_tasks, rank, world, costs)
+    t0 = time.perf_counter()
     if len(ids) == 0:
         if width is None:
             raise ValueError("sharded_map needs n_tasks >= world_size (or an explicit record width)")
         rec = np.zeros((0, int(width)))
     else:
         rec = fn(ids)
-    return gather_records(rec, ids, n_tasks, device=device)
+    busy = time.perf_counter() - t0
+    out = gather_records(rec, ids, n_tasks, device=device)
+    _record_stats("static", busy, len(ids), device)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dynamic dealing: chunks of the task list handed out on demand from a counter every rank can reach
+# ---------------------------------------------------------------------------------------------------------------
+_DEAL_SEQ = [0]
+
+
+class TaskDealer:
+    """Hands out the task list in chunks, on demand.  Under torch.distributed the position lives in the process
+    group's key-value store (`store.add` is atomic: the TCPStore torchrun already set up, no extra service), so a rank
+    that finishes early simply draws the next chunk - what Ray's scheduler did for the reference, one task at a time
+    (waveome/model_search.py:474-489, 1200-1222).  `order` (default: by decreasing cost, stable) is the same on every
+    rank; without a process group the counter is local.  Every rank must create its dealers in the same sequence
+    (the key is a per-process sequence number)."""
+
+    def __init__(self, n_tasks: int, chunk: int, costs: Optional[Sequence[float]] = None):
+        self.n, self.chunk = int(n_tasks), max(1, int(chunk))
+        self.order = (np.arange(self.n) if costs is None
+                      else np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable"))
+        self.taken = 0          # tasks this rank drew
+        self._local = 0
+        self._store = None
+        _DEAL_SEQ[0] += 1
+        self._key = f"waveome_amd/deal/{_DEAL_SEQ[0]}"
+        if dist_active():
+            from torch.distributed import distributed_c10d
+
+            self._store = distributed_c10d._get_default_store()
+
+    def pull(self) -> np.ndarray:
+        """The next chunk of task indices (empty once the list is exhausted)."""
+        if self._store is not None:
+            start = int(self._store.add(self._key, self.chunk)) - self.chunk
+        else:
+            start, self._local = self._local, self._local + self.chunk
+        ids = self.order[start:start + self.chunk] if start < self.n else self.order[:0]
+        self.taken += len(ids)
+        return ids
+
+
+def gather_ragged(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, width: int, device=None) -> np.ndarray:
+    """All-gather records of shards whose sizes are only known at run time (dynamic dealing): sizes first, then
+    buffers padded to the largest shard.  Returns [n_tasks, width] ordered by task id on every rank."""
+    rank, world = dist_info()
+    local_ids = np.asarray(local_ids, dtype=np.int64)
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(len(local_ids), int(width))
+    if not dist_active():
+        out = np.full((n_tasks, int(width)), np.nan)
+        out[local_ids] = local
+        return out
+    import torch
+
+    dist = _dist()
+    dev = collective_device(device)
+    cnt = torch.tensor([len(local_ids)], dtype=torch.int64, device=dev)
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cap = max(1, max(int(c.item()) for c in cnts))
+    buf = torch.full((cap, int(width) + 1), -1.0, dtype=torch.float64, device=dev)
+    if len(local_ids):
+        buf[:len(local_ids), 0] = torch.as_tensor(local_ids.astype(np.float64), device=dev)
+        buf[:len(local_ids), 1:] = torch.from_numpy(local).to(dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    out = np.full((n_tasks, int(width)), np.nan)
+    for b in bufs:
+        b = b.cpu().numpy()
+        keep = b[:, 0] >= 0
+        out[b[keep, 0].astype(np.int64)] = b[keep, 1:]
+    return out
+
+
+def dynamic_map(n_tasks: int, run: Callable[[Callable[[], np.ndarray]], tuple], chunk: int, width: int,
+                costs=None, device=None) -> np.ndarray:
+    """Dynamic counterpart of `sharded_map` for jobs whose tasks differ in cost in ways nobody knows beforehand
+    (fits run to SciPy's tolerances: 58 ... 395 iterations per fit in BASELINE config C4).
+
+    `run(pull)` does this rank's work: it calls `pull()` whenever it can take more tasks (an empty array = none
+    left), and returns (task ids, [len, width] records) for everything it drew.  Chunks are dealt heaviest first
+    (by `costs`) from a shared counter, so the ranks finish within about one chunk's work of each other; results do
+    not depend on who fitted what (a fit depends only on its task), so the gathered table is bit-identical to a
+    single-process run.  Per-rank busy times -> `last_map_stats()`."""
+    import time
+
+    dealer = TaskDealer(n_tasks, chunk, costs)
+    t0 = time.perf_counter()
+    ids, rec = run(dealer.pull)
+    busy = time.perf_counter() - t0
+    ids = np.asarray(ids, dtype=np.int64)
+    if len(ids) != dealer.taken:
+        raise RuntimeError(f"dynamic_map: run() returned {len(ids)} records for the {dealer.taken} tasks it drew")
+    out = gather_ragged(np.asarray(rec, dtype=np.float64).reshape(len(ids), int(width)), ids, n_tasks, width, device)
+    _record_stats("dynamic", busy, len(ids), device)
+    return out
+
+
+def pull_all(fn: Callable[[np.ndarray], np.ndarray]) -> Callable:
+    """Adapter: a `run` for dynamic_map out of a plain fn(ids) -> records, one call per chunk (CPU-side work; GPU
+    fits use `engine.Problem.fit_stream`, which keeps one batch full across chunks)."""
+    def run(pull):
+        all_ids, recs = [], []
+        while True:
+            ids = pull()
+            if len(ids) == 0:
+                break
+            all_ids.append(np.asarray(ids))
+            recs.append(np.asarray(fn(np.asarray(ids)), dtype=np.float64))
+        if not all_ids:
+            return np.zeros(0, dtype=np.int64), np.zeros((0, 0))
+        return np.concatenate(all_ids), np.concatenate(recs, axis=0)
+    return run
