@@ -438,3 +438,79 @@ def test_deep_search_keeps_names_structures_and_lineage_consistent():
     assert res["best_model"] == min((m["bic"], m["depth"], n) for n, m in models.items())[2]
     for parent, child in res["edges"]:
         assert parent in models
+
+
+# ---------------------------------------------------------------------------------------------
+# the unsynchronised search sharded over ranks by COLUMN (kernel_search.run_searches_sharded)
+# ---------------------------------------------------------------------------------------------
+_SHARDED_WORKER = r'''
+import os, pickle, sys
+sys.path.insert(0, os.environ["WV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WV_ROOT"], "tests"))
+import numpy as np
+import torch.distributed as dist
+import test_search as T
+from waveome_amd import kernel_search as ks, kernels as K, parallel
+from waveome_amd.model_search import GPSearch
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = parallel.dist_info()
+X, Y = T.search_data()
+Y["lin_dose_b"] = 0.7 * Y["lin_dose"] + 0.3 * Y["noise"]; Y["smooth_b"] = Y["smooth_t"] * 1.3
+gps = GPSearch(X, Y, categorical_vars=["grp"])
+Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+scorer = T.OracleScorer(Xn, Yn)
+session = T._DelayedOracleSession(scorer, seed=7 + rank)       # each rank's queue answers in its own scrambled order
+got = ks.run_searches_sharded(Yn.shape[1], 3, [K.SquaredExponential(), K.Lin()], scorer, cat_vars=[2], session=session,
+                              max_depth=3, keep_only_best=False)
+stats = parallel.last_map_stats()
+slim = {c: {"best": r["best_model"], "edges": r["edges"],
+            "models": {n: (m["bic"], m["parent"], m["depth"]) for n, m in r["models"].items()}} for c, r in got.items()}
+with open(os.environ["WV_OUT"] + f".{rank}", "wb") as fh:
+    pickle.dump({"res": slim, "stats": stats, "own_fits": scorer.n_fits, "totals": scorer.job_totals}, fh)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_column_sharded_unsynchronised_search_equals_single_process(tmp_path):
+    """gloo, world size 2, the CPU oracle as scorer behind a delaying / scrambling session: every column's search runs
+    on one rank, columns are dealt on demand, the gathered result on BOTH ranks equals the single-process search."""
+    import pickle
+    import socket
+    import subprocess
+
+    from waveome_amd.model_search import GPSearch
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "sharded")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), WV_ROOT=str(ROOT), WV_OUT=out, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", _SHARDED_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        log, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, log.decode()[-3000:]
+    X, Y = search_data()
+    Y["lin_dose_b"] = 0.7 * Y["lin_dose"] + 0.3 * Y["noise"]
+    Y["smooth_b"] = Y["smooth_t"] * 1.3
+    gps = GPSearch(X, Y, categorical_vars=["grp"])
+    Xn, Yn = gps.X.to_numpy(), gps.Y.to_numpy()
+    ref_scorer = OracleScorer(Xn, Yn)
+    ref = ks.run_searches(range(5), 3, [K.SquaredExponential(), K.Lin()], ref_scorer, cat_vars=[2], max_depth=3,
+                          keep_only_best=False)
+    parts = [pickle.load(open(out + f".{r}", "rb")) for r in range(2)]
+    assert parts[0]["res"] == parts[1]["res"]                       # every rank holds the whole job's result
+    for c in range(5):
+        got = parts[0]["res"][c]
+        assert got["best"] == ref[c]["best_model"] and got["edges"] == ref[c]["edges"]
+        assert got["models"] == {n: (m["bic"], m["parent"], m["depth"]) for n, m in ref[c]["models"].items()}
+    # the columns were split (nobody searched everything), the fit counts add up, the imbalance figure is there
+    assert all(0 < p["own_fits"] < ref_scorer.n_fits for p in parts)
+    assert parts[0]["own_fits"] + parts[1]["own_fits"] == ref_scorer.n_fits == parts[0]["totals"]["fits"]
+    st = parts[0]["stats"]
+    assert st["mode"] == "dynamic-columns" and sorted(st["tasks_per_rank"]) == [2, 3]
+    assert st["rank_time_max_over_mean"] >= 1.0

@@ -679,11 +679,14 @@ class _SearchSession:
 
 def run_searches_async(columns: Sequence[int], n_features: int, kern_list: Sequence, scorer: "GpuScorer",
                        cat_vars: Sequence[int] = (), verbose: bool = False, session=None,
+                       more_columns: Optional[Callable[[], Sequence[int]]] = None, keep_active: int = 0,
                        **search_kwargs) -> Dict[int, dict]:
     """The searches of `run_searches` without its lock step: every output column's generator gets the fits it asked
     for as soon as they are all done and its next candidates join the running work queue at once - as in the
     reference, where each column is its own Ray task (model_search.py:1200-1222).  Same fits (a fit depends only on
-    (structure, column)), hence the same search trees and best models; single process only.
+    (structure, column)), hence the same search trees and best models.
+    `more_columns` / `keep_active`: whenever fewer than `keep_active` searches are running, more columns are drawn
+    from `more_columns()` (empty: none left) - how the ranks of a job share the columns (`run_searches_sharded`).
     `session`: anything with request(col, kernel, callback) / busy() / pump() / close() (test seam)."""
     session = session or _SearchSession(scorer)
     gens, results = {}, {}
@@ -707,15 +710,30 @@ def run_searches_async(columns: Sequence[int], n_features: int, kern_list: Seque
         if not cands:
             ready.append(c)
 
+    def start(c):
+        g = full_kernel_search_steps(n_features, kern_list, cat_vars=cat_vars, **search_kwargs)
+        try:
+            req = next(g)
+            gens[c] = g
+            ask(c, req)
+        except StopIteration as e:  # pragma: no cover - a search always scores depth 1
+            results[c] = e.value
+
+    source = [more_columns]
+
+    def top_up():
+        while source[0] is not None and len(pending) < keep_active:
+            new = [int(c) for c in source[0]()]
+            if not new:
+                source[0] = None
+                break
+            for c in new:
+                start(c)
+
     try:
         for c in columns:
-            g = full_kernel_search_steps(n_features, kern_list, cat_vars=cat_vars, **search_kwargs)
-            try:
-                req = next(g)
-                gens[c] = g
-                ask(c, req)
-            except StopIteration as e:  # pragma: no cover - a search always scores depth 1
-                results[c] = e.value
+            start(int(c))
+        top_up()
         steps = 0
         while pending:
             while ready:
@@ -725,6 +743,9 @@ def run_searches_async(columns: Sequence[int], n_features: int, kern_list: Seque
                     ask(c, gens[c].send(st["fits"]))
                 except StopIteration as e:
                     results[c] = e.value
+            top_up()
+            if ready:
+                continue
             if not pending:
                 break
             if not session.busy():
@@ -737,6 +758,39 @@ def run_searches_async(columns: Sequence[int], n_features: int, kern_list: Seque
     finally:
         session.close()
     return results
+
+
+def run_searches_sharded(n_columns: int, n_features: int, kern_list: Sequence, scorer: "GpuScorer",
+                         cat_vars: Sequence[int] = (), verbose: bool = False, session=None,
+                         **search_kwargs) -> Dict[int, dict]:
+    """The unsynchronised search under torch.distributed: every output column's search runs entirely on ONE rank (its
+    generator never crosses ranks, so no level barrier anywhere - the reference's one Ray task per column,
+    model_search.py:1200-1222), the columns are dealt to the ranks on demand (`parallel.TaskDealer`: a rank starts
+    with three quarters of its fair share and draws more as its searches finish), and the per-column results are
+    all-gathered at the end (`parallel.gather_objects`).  Same fits as everywhere else, hence the same trees.
+    Per-rank busy times -> `parallel.last_map_stats()`."""
+    import time
+
+    rank, world = parallel.dist_info()
+    fair = -(-n_columns // world)
+    keep_active = max(1, -(-3 * fair // 4))
+    dealer = parallel.TaskDealer(n_columns, max(1, keep_active // 4))
+    t0 = time.perf_counter()
+    mine = run_searches_async([], n_features, kern_list, scorer, cat_vars=cat_vars, verbose=verbose, session=session,
+                              more_columns=dealer.pull, keep_active=keep_active, **search_kwargs)
+    busy = time.perf_counter() - t0
+    merged: Dict[int, dict] = {}
+    totals = [0, 0]
+    for part, n_fits, n_struct in parallel.gather_objects((mine, getattr(scorer, "n_fits", 0),
+                                                           getattr(scorer, "n_structures", 0))):
+        merged.update(part)
+        totals[0] += int(n_fits or 0)
+        totals[1] += int(n_struct or 0)
+    parallel._record_stats("dynamic-columns", busy, len(mine))
+    scorer.job_totals = {"fits": totals[0], "structures": totals[1]}
+    if sorted(merged) != list(range(n_columns)):
+        raise RuntimeError("sharded search: the ranks' column sets do not add up to the job")
+    return merged
 
 
 def run_searches(columns: Sequence[int], n_features: int, kern_list: Sequence, scorer: Callable,

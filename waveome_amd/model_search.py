@@ -443,12 +443,18 @@ class GPSearch:
         # (WV_SEARCH_ASYNC=0: level by level); under torch.distributed the levels are sharded over the ranks
         import os
 
-        use_async = (scorer.__class__ is ks.GpuScorer and scorer.mode == "multi" and not parallel.dist_active()
+        use_async = (scorer.__class__ is ks.GpuScorer and scorer.mode == "multi"
                      and os.environ.get("WV_SEARCH_ASYNC", "1") != "0")
-        drive = ks.run_searches_async if use_async else ks.run_searches
-        out = drive(range(P), Xn.shape[1], kernels, scorer, cat_vars=self.cat_idx, verbose=verbose,
-                    max_depth=max_depth, keep_all=keep_all, metric_diff=metric_diff,
-                    early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)
+        kw = dict(cat_vars=self.cat_idx, verbose=verbose, max_depth=max_depth, keep_all=keep_all,
+                  metric_diff=metric_diff, early_stopping=early_stopping, prune=prune, keep_only_best=keep_only_best)
+        if use_async and parallel.dist_active():
+            # every column's search lives on one rank, columns are dealt on demand, results gathered at the end
+            out = ks.run_searches_sharded(P, Xn.shape[1], kernels, scorer, **kw)
+            self.rank_stats = parallel.last_map_stats()
+        elif use_async:
+            out = ks.run_searches_async(range(P), Xn.shape[1], kernels, scorer, **kw)
+        else:  # level by level; under torch.distributed each level's candidates are dealt to the ranks
+            out = ks.run_searches(range(P), Xn.shape[1], kernels, scorer, **kw)
         self.models, self.search_info = {}, {}
         for p, feat in enumerate(self.out_names):
             res = out[p]
@@ -467,8 +473,9 @@ class GPSearch:
                 res["var_exp"] = calc_rsquare(mod)
             self.models[feat] = mod
             self.search_info[feat] = res
-        self.search_stats = {"fits": getattr(scorer, "n_fits", None),
-                             "structures": getattr(scorer, "n_structures", None),
+        totals = getattr(scorer, "job_totals", None) or {}
+        self.search_stats = {"fits": totals.get("fits", getattr(scorer, "n_fits", None)),
+                             "structures": totals.get("structures", getattr(scorer, "n_structures", None)),
                              "seconds": time.time() - start_time}
         elapsed_time = np.round((time.time() - start_time) / 60, 1)
         print(f"Finished {len(self.out_names)} models (100%),", f"elapsed time: {elapsed_time} minutes")

@@ -335,6 +335,31 @@ def gather_ragged(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, width:
     return out
 
 
+def gather_objects(obj, device=None) -> list:
+    """All-gather one picklable object per rank (the per-column search results of the sharded kernel search: kernels,
+    fit records); returns the list indexed by rank.  Pickled bytes travel as uint8 tensors on `collective_device`, so
+    it works under nccl (device memory) and gloo alike; without a process group it returns [obj]."""
+    if not dist_active():
+        return [obj]
+    import pickle
+
+    import torch
+
+    dist = _dist()
+    rank, world = dist_info()
+    dev = collective_device(device)
+    blob = np.frombuffer(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL), dtype=np.uint8)
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    sizes = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    cap = max(1, max(int(v.item()) for v in sizes))
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    buf[:len(blob)] = torch.from_numpy(blob.copy()).to(dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    return [pickle.loads(b.cpu().numpy()[:int(v.item())].tobytes()) for b, v in zip(bufs, sizes)]
+
+
 def dynamic_map(n_tasks: int, run: Callable[[Callable[[], np.ndarray]], tuple], chunk: int, width: int,
                 costs=None, device=None) -> np.ndarray:
     """Dynamic counterpart of `sharded_map` for jobs whose tasks differ in cost in ways nobody knows beforehand
