@@ -30,6 +30,10 @@ int32_t wv_dbg_mfma4_probe(wv_ctx* ctx, int32_t* table_out);
 /* float4-style streaming copy of `bytes` bytes, GB/s (read + write counted). */
 int32_t wv_dbg_copy_rate(wv_ctx* ctx, int64_t bytes, int32_t iters, double* gbps_out);
 
+/* Shader-clock stamps (8 x uint64) of workgroup 0 / thread 0 of the last small-tile GEMM launch: [0] entry, [1] first
+ * chunk in LDS, [2] end of the K loop, [3] end of the epilogue. */
+int32_t wv_dbg_gemm_stamps(unsigned long long* out);
+
 #ifdef __cplusplus
 }
 #endif

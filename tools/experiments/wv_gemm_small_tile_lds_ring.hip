@@ -1,3 +1,12 @@
+// EXPERIMENT, NOT BUILT - measured negative of round 3: wv_gemm.hip with the small 64 x 64 tile
+// of the few-fits regime run as a ring of three LDS stages (global loads four chunks ahead in four register sets, the
+// next chunk's fragments fetched across the chunk boundary, two k-steps ahead).  Correct and bit-identical (all GPU
+// parity tests passed), but not faster: one fit at N = 2048 1.96 -> 2.00 ms per evaluation.  In-kernel shader-clock
+// stamps (profiles/r03_small_tile_parts_*.txt) say why: a chunk of 64 MFMAs per wave costs ~1900 cycles of which
+// 1450 remain with NOTHING but the fragment reads and the MFMAs in the loop (1024 would be the matrix core's time) and
+// 1150 with everything but the MFMAs - a lone wave's LDS instructions (26 per chunk at this tile shape, 0.4 per MFMA)
+// hold up its own MFMA issue by ~16 cycles each, whatever their lead.  The lever is LDS instructions per MFMA (wave tile
+// shape), not prefetch depth.
 // Batched float64 GEMM family on v_mfma_f64_4x4x4_4b_f64 (gfx950).
 //
 // One kernel template serves every O(N^3) step of the evaluation:
@@ -157,10 +166,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   // one LDS block: [2][A tile] [2][B tile] during the K loop, re-used as a [64][BN + 2] staging
   // image of half the C tile in the epilogue
   constexpr int LDC = BN + 2;
-  constexpr int SMEM = 2 * (TA::SIZE + TB::SIZE) > 64 * LDC ? 2 * (TA::SIZE + TB::SIZE) : 64 * LDC;
+  constexpr int NSTG = SMALL ? 3 : 2;  // LDS stages of the K loop (the small tile runs a ring of three, see below)
+  constexpr int SMEM = NSTG * (TA::SIZE + TB::SIZE) > 64 * LDC ? NSTG * (TA::SIZE + TB::SIZE) : 64 * LDC;
   __shared__ __attribute__((aligned(16))) double smem[SMEM];
   double(*sA)[TA::SIZE] = reinterpret_cast<double(*)[TA::SIZE]>(smem);
-  double(*sB)[TB::SIZE] = reinterpret_cast<double(*)[TB::SIZE]>(smem + 2 * TA::SIZE);
+  double(*sB)[TB::SIZE] = reinterpret_cast<double(*)[TB::SIZE]>(smem + NSTG * TA::SIZE);
 
   // ---- block -> (batch, tile) with same-matrix tiles kept on one XCD (L2 reuse of panels).
   // g.tiles_live counts only the tiles that do work (lower tiles when g.tri): no workgroup is
@@ -201,8 +211,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
 #ifdef WV_EXPERIMENTS
     } else if (g.tri == 3 && g.tri_order == 1 && (g.tiles_m & 3) == 0) {
       // L2 experiment (WV_TRI_ORDER=1): the strictly-lower tiles in 4 x 4 super-blocks instead of row by row, so that
-      // the 64 tiles an XCD holds at a time touch ~16 operand panels instead of ~21.  Measured: no effect (+-0.5 %,
-      // profiles/r03_probe_tri_order_*.txt) - the product is not sensitive to operand re-fetch.
+      // the 64 tiles an XCD holds at a time touch ~16 operand panels instead of ~21
       int sbm = 0, sbn = 0;
       for (;;) {
         const int cnt = sbn < sbm ? 16 : 6;
@@ -327,24 +336,28 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   uint32_t offa[TA::NLOAD], offb[TB::NLOAD];
   TA::goffsets(offa, g.lda, m0, g.M, tid);
   TB::goffsets(offb, g.ldb, n0, g.N, tid);
-  if (nchunk > 0) {
-    TA::gload(ra, TA::chunk_base(A, g.lda, m0, kb), offa);
-    TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kb), offb);
-    TA::sstore(sA[0], ra, tid);
-    TB::sstore(sB[0], rb, tid);
-  }
-  __syncthreads();
-  WV_GSTAMP(1);
-  for (int c = 0; c < nchunk; ++c) {
-    const int cur = c & 1;
-    if (c + 1 < nchunk && !WV_X(4)) {
-      const int kn = kb + (c + 1) * kstep;
-      TA::gload(ra, TA::chunk_base(A, g.lda, m0, kn), offa);
-      TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
-    }
+  // small tile: fragments are fetched TWO k-steps ahead (one k-step is 16 MFMAs = 256 cycles, less than an LDS round
+  // trip: with one k-step of lead the K loop took 1430 cycles per chunk with nothing but reads and MFMAs in it, against
+  // 1024 of matrix-core time; profiles/r03_small_tile_parts_ring.txt), into one buffer per k-step of a chunk: on entry
+  // of compute_chunk buffers 0 and 1 hold the chunk's first two k-steps, its last two fetch the next chunk's
+  double af_s[4][4], bq_s[4][4];
+  auto fetch_small = [&](const double* __restrict__ a_st, const double* __restrict__ b_st, int s, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af_s[buf][i] = a_st[TA::at(i * 16 + fr, s * 4 + fk)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bq_s[buf][r] = b_st[TB::at(wn * WCOLS + brot[r], s * 4 + fk)];
+  };
+  // the MFMAs of chunk c on LDS stage `cur` (`nxt`: the stage of chunk c + 1, small tile only)
+  auto compute_chunk = [&](int c, int cur, int nxt) {
     const double* __restrict__ a_s = sA[cur];
     const double* __restrict__ b_s = sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
+    if constexpr (SMALL) {
+      if (!(kc0 >= wkb && kc0 < wke)) {  // nothing to multiply: only keep the pipeline fed
+        fetch_small(sA[nxt], sB[nxt], 0, 0);
+        fetch_small(sA[nxt], sB[nxt], 1, 1);
+      }
+    }
     if (kc0 >= wkb && kc0 < wke && !WV_X(8)) {
       if constexpr (TRIOPT) {
         if (half) mma_chunk_diag<false, TA, TB, NJ>(acc, a_s, b_s, 64, ecol, brot, fr, fk);
@@ -363,23 +376,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
           constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
           if constexpr (SMALL && !NOLDS) {
             // small tile: 16 MFMAs per k-step cannot hide the LDS latency of their own 8 fragment reads, and at ~100
-            // VGPRs there is room to fetch the next k-step's fragments while this one's MFMAs run
-            double af[2][4], bq[2][4];
-            auto fetch = [&](int s, int buf) {
-#pragma unroll
-              for (int i = I0; i < I1; ++i) af[buf][i] = a_s[TA::at(i * 16 + fr, s * 4 + fk)];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) bq[buf][r] = b_s[TB::at(wn * WCOLS + brot[r], s * 4 + fk)];
-            };
-            fetch(0, 0);
+            // VGPRs there is room to fetch the next k-step's fragments while this one's MFMAs run - across the chunk
+            // boundary too: the last k-step fetches the first fragments of chunk c + 1 from its stage of the ring
 #pragma unroll
             for (int s = 0; s < KC / 4; ++s) {
-              if (s + 1 < KC / 4) fetch(s + 1, (s + 1) & 1);
+              if (s + 2 < KC / 4) fetch_small(a_s, b_s, s + 2, s + 2);
+              else fetch_small(sA[nxt], sB[nxt], s + 2 - KC / 4, s + 2 - KC / 4);
 #pragma unroll
               for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = I0; i < I1; ++i)
-                  acc[i][0][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[s & 1][i], bq[s & 1][r], acc[i][0][r], 0, 0, 0);
+                  acc[i][0][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af_s[s][i], bq_s[s][r], acc[i][0][r], 0, 0, 0);
+              // pin the order: this k-step's prefetch reads are ISSUED before its MFMAs (the scheduler otherwise sinks them
+              // towards their uses, two k-steps later, and the lead is gone)
+              __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, (I1 - I0) * 4, 0);
             }
             return;
           }
@@ -436,11 +447,90 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
         }
       }
     }
-    if (c + 1 < nchunk) {
-      TA::sstore(sA[cur ^ 1], ra, tid);
-      TB::sstore(sB[cur ^ 1], rb, tid);
+  };
+  if constexpr (SMALL) {
+    // Few fits in flight: a workgroup is alone on its CU, so whatever one chunk exposes is paid in full, 8 to 128 times
+    // per product (r02_timeline_one_fit_2048.txt: ~0.8 us per chunk of 64 MFMAs per wave = 0.43 us of matrix-core
+    // time).  Measured first: three chunks of global loads in flight instead of one changed nothing - it is not the
+    // operands' arrival.  It is the chain ds_write -> s_barrier -> ds_read -> first MFMA between any two chunks.  So the
+    // small tile runs a ring of THREE LDS stages: chunk c + 2 is written to LDS while chunk c is multiplied, the
+    // barrier at the end of an iteration only protects the stage that is overwritten next (nobody waits for fresh
+    // data behind it), and the first fragments of chunk c + 1 are already in registers when it starts (compute_chunk).
+    // Global loads run four chunks ahead in four register sets (a chunk is requested at iteration c - 4 and written
+    // to LDS at c - 2).  Requests and deposits are UNCONDITIONAL (past the end they repeat the last chunk into a stage
+    // nobody reads): a branch around a load makes the compiler's s_waitcnt insertion assume the fewest loads in
+    // flight at the join and wait for ALL of them before every deposit, which serialises the chunks again.
+    d2 ra4[4][TA::NLOAD], rb4[4][TB::NLOAD];
+    const int lastc = max(nchunk - 1, 0);
+    auto request = [&](auto setc, int c) {
+      constexpr int S = decltype(setc)::value;
+      const int kn = kb + min(c, lastc) * kstep;
+      TA::gload(ra4[S], TA::chunk_base(A, g.lda, m0, kn), offa);
+      TB::gload(rb4[S], TB::chunk_base(B, g.ldb, n0, kn), offb);
+    };
+    auto deposit = [&](auto setc, int stage) {
+      constexpr int S = decltype(setc)::value;
+      TA::sstore(sA[stage], ra4[S], tid);
+      TB::sstore(sB[stage], rb4[S], tid);
+    };
+    using std::integral_constant;
+    using s0 = integral_constant<int, 0>; using s1 = integral_constant<int, 1>;
+    using s2 = integral_constant<int, 2>; using s3 = integral_constant<int, 3>;
+    if (nchunk > 0) {  // (an empty range - block structures - must not touch the operands at all)
+      request(s0{}, 0);
+      request(s1{}, 1);
+      request(s2{}, 2);
+      request(s3{}, 3);
+      deposit(s0{}, 0);
+      deposit(s1{}, 1);
     }
-    if (!WV_X(16)) __syncthreads();
+    __syncthreads();
+    if (nchunk > 0) {
+      fetch_small(sA[0], sB[0], 0, 0);
+      fetch_small(sA[0], sB[0], 1, 1);
+    }
+    WV_GSTAMP(1);
+    int stage = 0;  // = c % 3
+    // set S held chunk c (in LDS since iteration c - 2) and takes chunk c + 4; set S2 holds chunk c + 2
+    auto step = [&](auto setc, auto set2c, int c) {
+      const int nxt = stage == 2 ? 0 : stage + 1, prv = stage == 0 ? 2 : stage - 1;
+      if (!WV_X(4)) request(setc, c + 4);
+      if (!WV_X(64)) deposit(set2c, prv);  // chunk c + 2 into the stage chunk c - 1 has left (free since the last barrier);
+      compute_chunk(c, stage, nxt);        // first, so that the writes complete behind this chunk's MFMAs
+      if (!WV_X(16)) __syncthreads();
+      stage = nxt;
+    };
+    int c = 0;
+    for (; c + 3 < nchunk; c += 4) {
+      step(s0{}, s2{}, c);
+      step(s1{}, s3{}, c + 1);
+      step(s2{}, s0{}, c + 2);
+      step(s3{}, s1{}, c + 3);
+    }
+    if (c < nchunk) step(s0{}, s2{}, c);
+    if (c + 1 < nchunk) step(s1{}, s3{}, c + 1);
+    if (c + 2 < nchunk) step(s2{}, s0{}, c + 2);
+  } else {
+    if (nchunk > 0) {
+      TA::gload(ra, TA::chunk_base(A, g.lda, m0, kb), offa);
+      TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kb), offb);
+      TA::sstore(sA[0], ra, tid);
+      TB::sstore(sB[0], rb, tid);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk && !WV_X(4)) {
+        const int kn = kb + (c + 1) * kstep;
+        TA::gload(ra, TA::chunk_base(A, g.lda, m0, kn), offa);
+        TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
+      }
+      compute_chunk(c, c & 1, (c & 1) ^ 1);
+      if (c + 1 < nchunk) {
+        TA::sstore(sA[(c & 1) ^ 1], ra, tid);
+        TB::sstore(sB[(c & 1) ^ 1], rb, tid);
+      }
+      if (!WV_X(16)) __syncthreads();
+    }
   }
 
   // ---- epilogue: C = beta*C + alpha*acc.  D lane 16 i' + 4 blk + j of accumulator (i, j, r)

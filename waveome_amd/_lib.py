@@ -125,6 +125,7 @@ PROBE_SIGNATURES = {
     "wv_dbg_valu_f64_rate": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "wv_dbg_mfma4_probe": (C.c_int32, [_vp, _ip]),
     "wv_dbg_copy_rate": (C.c_int32, [_vp, C.c_int64, C.c_int32, _dp]),
+    "wv_dbg_gemm_stamps": (C.c_int32, [C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

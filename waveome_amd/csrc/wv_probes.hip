@@ -152,7 +152,12 @@ static int32_t dbg_gemm_bench_impl(wv_ctx* ctx, int32_t M, int32_t N, int32_t K,
   return WV_OK;
 }
 
+namespace wv { int read_gemm_stamps(unsigned long long* out); }
+
 extern "C" {
+
+/* shader-clock stamps of workgroup 0 of the last small-tile GEMM launch: entry, first chunk in LDS, end of the K loop, end */
+int32_t wv_dbg_gemm_stamps(unsigned long long* out) { return wv::read_gemm_stamps(out); }
 
 int32_t wv_dbg_gemm_bench(wv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_kc, int32_t b_kc,
                           int32_t bn, int32_t nbatch, int32_t iters, double* tflops_out, double* ms_out) {
