@@ -421,6 +421,8 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
 }
 
 // sum over (unmasked) terms of the product of their factors, on the thread's 4 x 4 elements
+// (MULTI = false: every factor acts on one column - the paths that keep 4 x 4 distance arrays are not instantiated)
+template <bool MULTI = true>
 __device__ inline void kernel_sum_tile(const DevSpec* __restrict__ sp, const TileCtx& t, uint64_t term_mask,
                                        double (&sum)[4][4]) {
   const int16_t* slots = sp->fslots;
@@ -433,11 +435,11 @@ __device__ inline void kernel_sum_tile(const DevSpec* __restrict__ sp, const Til
     if (!((term_mask >> term) & 1ull)) continue;  // leave-component-out Gram matrices
     const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
     if (f1 - f0 == 1) {
-      factor_tile<1>(sp->factors[f0], t.fc + 4 * f0, slots, t, sum, sum, dummy_s);
+      factor_tile<1, MULTI>(sp->factors[f0], t.fc + 4 * f0, slots, t, sum, sum, dummy_s);
       continue;
     }
-    factor_tile<0>(sp->factors[f0], t.fc + 4 * f0, slots, t, prod, prod, dummy_s);
-    for (int f = f0 + 1; f < f1; ++f) factor_tile<3>(sp->factors[f], t.fc + 4 * f, slots, t, prod, prod, dummy_s);
+    factor_tile<0, MULTI>(sp->factors[f0], t.fc + 4 * f0, slots, t, prod, prod, dummy_s);
+    for (int f = f0 + 1; f < f1; ++f) factor_tile<3, MULTI>(sp->factors[f], t.fc + 4 * f, slots, t, prod, prod, dummy_s);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -469,8 +471,11 @@ __device__ inline bool tile_is_zero(const int32_t* __restrict__ span, int ti, in
 constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup) ...
 constexpr int FEW_FITS = 8;  // ... but ONE with at most this many fits in flight: more, shorter workgroups (latency regime)
 
-template <typename R, bool MASKED>  // MASKED: missing outputs (row masks per output column), see trace_kernel
-__global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict__ specs,
+// MASKED: missing outputs (row masks per output column), see trace_kernel.  MULTI = false: every factor of every
+// structure of the problem acts on ONE column (what full_kernel_build produces) - fewer live registers, more waves.
+// W4: held to 128 VGPRs (4 waves per SIMD, ~31 VGPRs spilled) instead of 3 waves - WV_GRAM_WAVES picks, scheduling only.
+template <typename R, bool MASKED, bool MULTI, bool W4 = false>
+__global__ __launch_bounds__(256, W4 ? 4 : 3) void gram_kernel(const DevSpec* __restrict__ specs,
                                                    const int32_t* __restrict__ slot_spec,
                                                    const double* __restrict__ F, const double* __restrict__ FC,
                                                    const double* __restrict__ theta_all,
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void gram_kernel(const DevSpec* __restrict_
       stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
       stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
       __syncthreads();
-      kernel_sum_tile(sp, t, term_mask, sum);
+      kernel_sum_tile<MULTI>(sp, t, term_mask, sum);
     }
     bool live_j[4];  // (padding rows and rows whose output is missing are identity rows / columns of K_y)
 #pragma unroll
@@ -757,13 +762,27 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
                           double diag) {
   const int tpw = gram_tpw(nb);
   dim3 grid((p.ntiles() + tpw - 1) / tpw, nb), blk(256);
-#define WV_GRAM_LAUNCH(MA)                                                                                              \
-  if (exp_table_ok<gram_kernel<R, MA>>())                                                                               \
-  hipLaunchKernelGGL((gram_kernel<R, MA>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst,   \
+#define WV_GRAM_LAUNCH(MA, MU)                                                                                          \
+  if (exp_table_ok<gram_kernel<R, MA, MU>>())                                                                           \
+  hipLaunchKernelGGL((gram_kernel<R, MA, MU>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, \
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask, \
                      diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
-  if (p.dmask) { WV_GRAM_LAUNCH(true); }
-  else { WV_GRAM_LAUNCH(false); }
+  static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
+  // (measured, 512 fits at N = 2048, same box: 7.02 ms at 3 waves per SIMD, 6.69 at 4 with 31 VGPRs spilled)
+  static const int waves = [] { const char* e = getenv("WV_GRAM_WAVES"); return e ? atoi(e) : 4; }();
+  const bool multi = p.any_multidim || force_multi;
+  if (p.dmask) {
+    if (multi) { WV_GRAM_LAUNCH(true, true); } else { WV_GRAM_LAUNCH(true, false); }
+  } else if (multi) {
+    WV_GRAM_LAUNCH(false, true);
+  } else if (waves == 4) {
+    if (exp_table_ok<gram_kernel<R, false, false, true>>())
+      hipLaunchKernelGGL((gram_kernel<R, false, false, true>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat,
+                         p.dfconst, p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper,
+                         term_mask, diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask);
+  } else {
+    WV_GRAM_LAUNCH(false, false);
+  }
 #undef WV_GRAM_LAUNCH
 }
 
