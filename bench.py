@@ -169,9 +169,11 @@ def pmc_traffic(fits_per_launch):
 
 
 def mfma_busy_profile():
-    """MFMA-busy fraction per GEMM launch of one 512-fit evaluation round (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE,
-    a separate rocprofv3 --pmc pass; the counters cannot be read from inside this process), from the newest committed
-    summary under profiles/ - the trailing update of the Cholesky recursion level by level among them."""
+    """MFMA-busy fraction of the GEMM launches of one 512-fit evaluation round (SQ_VALU_MFMA_BUSY_CYCLES /
+    GRBM_GUI_ACTIVE, a rocprofv3 --pmc pass of tools/prof_eval.py 512 1; the counters cannot be read from inside this
+    process), from the newest committed summary under profiles/: the Cholesky trailing update A22 -= S S' level by level
+    (its own kernel symbol <..., 0, 2>; h = rows of the update, from the launch's grid), K_y^-1 = M'M and its diagonal
+    launch."""
     import csv
     import glob
 
@@ -181,9 +183,25 @@ def mfma_busy_profile():
     try:
         with open(files[-1]) as fh:
             rows = list(csv.DictReader(fh))
-        return {"source": "profiles/" + os.path.basename(files[-1]), "rows": rows[:24]}
     except (OSError, ValueError):
         return None
+    out = {"source": "profiles/" + os.path.basename(files[-1]), "trailing_update_by_level": {}, "fits": 512}
+    for r in rows:
+        k, busy, us = r["kernel"], float(r["mfma_busy"]), float(r["dur_us"])
+        if k.endswith("128, 2, 0, 2>"):
+            tiles = int(r["grid"]) // 256 // 512          # strictly-lower 128-tiles per matrix: m (m - 1) / 2
+            m = int(round((1 + (1 + 8 * tiles) ** 0.5) / 2))
+            lvl = out["trailing_update_by_level"].setdefault(f"h={128 * m}", {"busy": [], "us": []})
+            lvl["busy"].append(busy)
+            lvl["us"].append(us)
+        elif k.endswith("128, 2, 0, 1>"):
+            out["mtm_lower_tiles"] = {"busy": busy, "us": us}
+        elif k.endswith("128, 2, 0, 5>"):
+            out["mtm_diagonal_tiles"] = {"busy": busy, "us": us}
+    for lvl in out["trailing_update_by_level"].values():
+        lvl["busy"] = round(sum(lvl["busy"]) / len(lvl["busy"]), 3)
+        lvl["us"] = round(sum(lvl["us"]) / len(lvl["us"]), 1)
+    return out
 
 
 def bench_c5(args):
