@@ -258,7 +258,10 @@ int32_t wv_fit_multi(wv_problem* prob, const int32_t* col_idx, const int32_t* sp
  * one batch group), fetch finished fits, submit what they unlock.  New kernel structures are added to the problem
  * with wv_problem_add_spec; the problem must have been created with room for them (wv_problem_create_ex).
  * Fits are bit-identical to wv_fit_multi's: a batch slot's arithmetic does not depend on its neighbours.
- * One queue per problem at a time; not thread-safe (like the problem itself). */
+ * One queue per problem at a time, and enforced: while a queue is open the groups' staging buffers and slots are
+ * the queue's - a second wv_queue_create and every other device entry point on that problem (wv_fit*, wv_lml,
+ * wv_value_grad, wv_gram, wv_predict, wv_whitened_means) answer WV_E_BADARG until wv_queue_destroy; wv_problem_add_spec
+ * stays allowed.  Not thread-safe (like the problem itself). */
 typedef struct wv_queue wv_queue;
 typedef struct {
   int32_t max_specs;   /* kernel structures the problem can hold */
@@ -286,7 +289,8 @@ int32_t wv_queue_submit(wv_queue* q, int32_t n, const int32_t* col_idx, const in
 /* One scheduling step (returns at once when nothing is queued or in flight).  n_done_out: finished fits waiting to
  * be fetched; n_in_system_out: tasks queued or being fitted. */
 int32_t wv_queue_advance(wv_queue* q, int32_t* n_done_out, int32_t* n_in_system_out);
-/* Up to cap finished fits, oldest first; theta_u_out is cap x u_stride. */
+/* Up to cap finished fits, oldest first; theta_u_out is cap x u_stride.  If a fit is wider than u_stride the call
+ * returns WV_E_BADARG with *n_out = the fits delivered before it (they are the caller's); the wide one stays queued. */
 int32_t wv_queue_fetch(wv_queue* q, int32_t cap, int32_t u_stride, int64_t* tags_out, double* theta_u_out,
                        double* loss_out, double* lml_out, int32_t* n_iter_out, int32_t* n_eval_out,
                        int32_t* status_out, int32_t* n_out);
