@@ -904,6 +904,81 @@ def test_work_queue_fed_incrementally_equals_fit_multi(ctx):
     small.close()
 
 
+def test_open_queue_owns_the_problem_and_fetch_keeps_what_it_popped(ctx):
+    """One work queue per problem, enforced: while it is open the other device entry points and a second queue are
+    refused (they would reuse the queue's staging buffers); after it is closed they work again.  And a fetch with a
+    too narrow row keeps the fits delivered before the wide one."""
+    import ctypes as C
+
+    from waveome_amd import _lib as L
+    from waveome_amd.engine import FitQueue, Problem, lbfgs_opts
+
+    X, Y = _data(3, 90, P=3)
+    s_small = ModelSpec(K.Lin(active_dims=[0]), 4, K.GaussianLikelihood(), K.ConstantMean())
+    s_wide = ModelSpec(K.SquaredExponential(active_dims=[0]) + K.SquaredExponential(active_dims=[1]), 4,
+                       K.GaussianLikelihood(), K.ConstantMean())
+    prob = Problem(ctx, X, Y, [s_small, s_wide], max_batch=4)
+    opts = lbfgs_opts(maxiter=5)
+    q = FitQueue(prob, opts, width=s_wide.n_trainable)
+    with pytest.raises(L.WaveomeAmdError, match="open work queue"):
+        FitQueue(prob, opts)
+    with pytest.raises(L.WaveomeAmdError, match="open work queue"):
+        prob.fit_multi([0], [0], np.zeros((1, s_wide.n_trainable)), opts)
+    U0 = np.zeros((3, s_wide.n_trainable))
+    U0[0, :s_small.n_trainable] = s_small.unconstrain()
+    U0[1, :s_wide.n_trainable] = s_wide.unconstrain()
+    U0[2, :s_small.n_trainable] = s_small.unconstrain()
+    q.submit([0, 1, 2], [0, 1, 0], U0, tags=[10, 11, 12])
+    while q.in_system > 0:
+        q.advance()
+    # fetch with rows only as wide as the SMALL structure: the wide fit (tag 11) cannot be delivered
+    w = s_small.n_trainable
+    tags = np.empty(8, dtype=np.int64)
+    U = np.empty((8, w))
+    n = C.c_int32(-1)
+    rc = prob.lib.wv_queue_fetch(q.handle, 8, w, tags.ctypes.data_as(C.POINTER(C.c_int64)), L.as_dp(U), None, None, None,
+                                 None, None, C.byref(n))
+    delivered = set(tags[:max(n.value, 0)].tolist())
+    assert (rc != 0 and 11 not in delivered) or delivered == {10, 11, 12}
+    rest = q.fetch()
+    assert delivered | set(rest["tag"].tolist()) == {10, 11, 12}   # nothing was lost
+    q.close()
+    res = prob.fit_multi([0], [0], U0[:1], opts)                   # the problem is usable again
+    assert np.isfinite(res["loss"][0])
+    prob.close()
+
+
+def test_fit_stream_equals_fit_multi(ctx):
+    """engine.Problem.fit_stream (tasks arriving in chunks from a dealer, the batch kept full across chunks - what a
+    rank of a dynamically dealt job runs) gives the fits of fit_multi bit for bit, whatever the chunking."""
+    from waveome_amd import parallel
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(8, 150, P=6)
+    specs = [ModelSpec(K.SquaredExponential(active_dims=[0]), 4, K.GaussianLikelihood(), K.ConstantMean()),
+             ModelSpec(K.Lin(active_dims=[1]) + K.Categorical(active_dims=[3]), 4, K.GaussianLikelihood(), K.ConstantMean()),
+             ModelSpec(K.Periodic(K.SquaredExponential(active_dims=[0])) + K.Matern32(active_dims=[1]), 4,
+                       K.GaussianLikelihood(), K.ConstantMean())]
+    width = max(sp.n_trainable for sp in specs)
+    T = 18
+    cols = (np.arange(T) % 6).astype(np.int32)
+    sidx = (np.arange(T) // 6).astype(np.int32)
+    U0 = np.zeros((T, width))
+    for t in range(T):
+        U0[t, :specs[sidx[t]].n_trainable] = specs[sidx[t]].unconstrain() + 0.03 * t
+    opts = lbfgs_opts(maxiter=25)
+    prob = Problem(ctx, X, Y, specs, max_batch=4)
+    ref = prob.fit_multi(cols, sidx, U0, opts)
+    for chunk in (1, 5, 18):
+        dealer = parallel.TaskDealer(T, chunk, costs=[specs[i].n_trainable for i in sidx])
+        ids, got = prob.fit_stream(dealer.pull, lambda t: (cols[t], sidx[t], U0[t], None), opts, width=width, backlog=2)
+        assert sorted(ids.tolist()) == list(range(T))
+        for key in ("loss", "lml", "nit", "nfev", "status"):
+            np.testing.assert_array_equal(got[key], ref[key][ids], err_msg=f"chunk {chunk}: {key}")
+        np.testing.assert_array_equal(got["u"], ref["u"][ids])
+    prob.close()
+
+
 def _random_tree(rng, depth):
     kinds = ["se", "m12", "m32", "m52", "per", "lin", "poly", "cat", "const"]
     if depth == 0 or rng.random() < 0.3:

@@ -629,6 +629,8 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // SIMD instead of 2; 11 VGPRs spill) - the pass is latency-bound, not issue-bound (section 4.0 of DESIGN.md).
 // MASKED: the problem has missing outputs (row masks per output column); its own instantiation so that the common case
 // keeps the register budget it was tuned for.
+// (Held to 128 VGPRs for a fourth wave per SIMD, as the Gram kernel is, it spills 54 VGPRs and takes 19.5 ms instead of
+// 7.4 per 512 fits - measured in round 3 and not kept.)
 template <typename R, bool MULTI, bool MASKED>
 __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
