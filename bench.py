@@ -326,7 +326,11 @@ def main():
     P = args.tasks * world
     dist = torch = None
     dev = None
-    if world > 1:
+    # WV_BENCH_DIST=1 (with torch.distributed.run --nproc-per-node 1): take the N > 1 path - process group, broadcast of
+    # the inputs, device-pointer problem, per-step all-gather - at world size 1, which is how the RCCL path is rehearsed
+    # on a one-GPU box
+    distributed = world > 1 or os.environ.get("WV_BENCH_DIST") == "1"
+    if distributed:
         import torch
         import torch.distributed as dist
 
@@ -366,7 +370,7 @@ def main():
 
     def barrier():
         ctx.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             if dev is not None:
                 torch.cuda.synchronize()
@@ -395,7 +399,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rank_busy = [busy[0]]
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -406,7 +410,7 @@ def main():
     dom_stage = prob.stage_times()[DOMINANT_STAGE]
     stages = None
     wall_used = time.perf_counter() - T_PROCESS_START
-    if rank == 0 and world == 1 and not args.no_breakdown and wall_used < WALL_BUDGET_S - 60:
+    if rank == 0 and not distributed and not args.no_breakdown and wall_used < WALL_BUDGET_S - 60:
         prob.timing(True)
         prob.timing_reset()
         n_b = min(len(my_cols), args.batch)
@@ -470,12 +474,12 @@ def main():
                            for k in GEMM_STAGES if stages[k]["ms"] > 0},
                 "GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in stages.items()
                          if v["bytes"] > 0 and v["ms"] > 0}}
-        if world == 1 and not args.no_cpu_baseline:
+        if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_finish(cpu_raw, float(table[:, 3].mean()))
         print(json.dumps(out), flush=True)
     prob.close()
     ctx.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
