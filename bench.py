@@ -330,6 +330,11 @@ def main():
     # the inputs, device-pointer problem, per-step all-gather - at world size 1, which is how the RCCL path is rehearsed
     # on a one-GPU box
     distributed = world > 1 or os.environ.get("WV_BENCH_DIST") == "1"
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner
+    # to fd 1 when the process group comes up): park the real stdout and point fd 1 at stderr until the line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if distributed:
         import torch
         import torch.distributed as dist
@@ -476,7 +481,8 @@ def main():
                          if v["bytes"] > 0 and v["ms"] > 0}}
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_finish(cpu_raw, float(table[:, 3].mean()))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     prob.close()
     ctx.close()
     if distributed:
