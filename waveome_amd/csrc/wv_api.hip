@@ -397,6 +397,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     p.max_fact = std::max(p.max_fact, (int)hspecs[si].n_factors);
     p.max_red = std::max(p.max_red, (int)hspecs[si].n_red);
     for (int fi = 0; fi < hspecs[si].n_factors; ++fi) p.any_multidim |= hspecs[si].factors[fi].ndims > 1;
+    p.any_product |= hspecs[si].n_factors > hspecs[si].n_terms;
   }
   p.spec_cap = n_specs;
   if (caps) {  // room for structures added later (wv_problem_add_spec)
@@ -409,7 +410,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     p.max_feat = std::max(p.max_feat, (int)caps->max_feat);
     p.max_fact = std::max(p.max_fact, (int)caps->max_factors);
     p.max_red = std::max(p.max_red, (int)caps->max_red);
-    if (caps->max_specs > n_specs) p.any_multidim = true;  // (later structures may act on several columns: the general trace kernel)
+    if (caps->max_specs > n_specs) p.any_multidim = p.any_product = true;  // (later structures may act on several columns or carry products: the general kernels)
   }
   p.specs.reserve(p.spec_cap);
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride

@@ -184,6 +184,7 @@ struct Problem {
   double *dfconst = nullptr;      // [max_batch][max_fact][4] per-factor constants derived from theta (see wv_gram.hip)
   int max_fact = 0, max_red = 1;  // largest n_factors / n_red over the problem's structures
   bool any_multidim = false;      // some factor of some structure acts on more than one column
+  bool any_product = false;       // some structure has a product term (or may get one: capacity for later structures)
   int spec_cap = 0;               // entries of the device structure table (>= specs.size(): wv_problem_add_spec)
   double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants

@@ -631,8 +631,10 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // keeps the register budget it was tuned for.
 // (Held to 128 VGPRs for a fourth wave per SIMD, as the Gram kernel is, it spills 54 VGPRs and takes 19.5 ms instead of
 // 7.4 per 512 fits - measured in round 3 and not kept.)
-template <typename R, bool MULTI, bool MASKED>
-__global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec* __restrict__ specs,
+// PROD = false: no structure of the problem has a product term (sums of single factors - the headline, C2, C5 and most
+// kernel-search candidates): the 4 x 4 copy of the weights that products need is not instantiated.
+template <typename R, bool MULTI, bool MASKED, bool PROD = true, bool W4 = false>
+__global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ F, const double* __restrict__ FC,
                                                     const double* __restrict__ theta_all,
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void trace_kernel(const DevSpec
         const DevFactor fg = sp->factors[g];
         if (fg.trainable == 0) continue;
         double s[3], unused[4][4];
-        if (f1 - f0 == 1) {
+        if (!PROD || f1 - f0 == 1) {
           factor_tile<2, MULTI>(fg, t.fc + 4 * g, slots, t, unused, w, s);
         } else {
           double wo[4][4];
@@ -828,7 +830,19 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   } while (0)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
-  if (p.f32) {
+  // (512 fits at N = 2048, same box: general kernel 7.4 ms; without the product paths 7.03 at 3 waves per SIMD - 140
+  // VGPRs, nothing spilled - and 6.68 at 4 waves - 128 VGPRs, 10 spilled; WV_TRACE_WAVES=3 selects the former)
+  static const int waves = [] { const char* e = getenv("WV_TRACE_WAVES"); return e ? atoi(e) : 4; }();
+  if (!p.f32 && !multi && !p.any_product && !p.dmask) {  // sums of single-column factors, float64, no missing outputs
+#define WV_TRACE_SUM(W4)                                                                                              \
+  if (exp_table_ok<trace_kernel<double, false, false, false, W4>>())                                                   \
+  hipLaunchKernelGGL((trace_kernel<double, false, false, false, W4>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, \
+                     p.dfconst, p.dtheta, p.Kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0,        \
+                     p.ntiles(), tpw, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol,  \
+                     p.dmask)
+    if (waves == 4) { WV_TRACE_SUM(true); } else { WV_TRACE_SUM(false); }
+#undef WV_TRACE_SUM
+  } else if (p.f32) {
     if (multi) WV_TRACE_LAUNCH(float, true, p.Kbuf32);
     else WV_TRACE_LAUNCH(float, false, p.Kbuf32);
   } else {
