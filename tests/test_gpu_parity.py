@@ -979,6 +979,77 @@ def test_fit_stream_equals_fit_multi(ctx):
     prob.close()
 
 
+_GROUPS_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from waveome_amd import ModelSpec, kernels as K
+from waveome_amd.engine import Context, FitQueue, Problem, lbfgs_opts
+
+rng = np.random.default_rng(17)
+N = 130
+X = rng.normal(size=(N, 2))
+Y = np.stack([np.sin(X[:, 0] * (1 + 0.4 * p)) + 0.2 * p * X[:, 1] + 0.1 * rng.normal(size=N) for p in range(7)], axis=1)
+spec = ModelSpec(K.SquaredExponential(active_dims=[0]) + K.Lin(active_dims=[1]), 2, K.GaussianLikelihood(), K.ConstantMean())
+ctx = Context(0)
+prob = Problem(ctx, X, Y, [spec], max_batch=6, capacity={"max_specs": 1})
+opts = lbfgs_opts(maxiter=400)
+T = 13
+cols = (np.arange(T) % 7).astype(np.int32)
+U0 = np.tile(spec.unconstrain(), (T, 1)) + 0.15 * rng.normal(size=(T, spec.n_trainable))
+whole = prob.fit_multi(cols, np.zeros(T, dtype=np.int32), U0, opts)          # more tasks than slots, run dry
+# the same tasks fed in two instalments: the second arrives when the first has drained to one or two fits in
+# flight - with several batch groups that is after the drain fold has parked fits (ADVICE r02: they must not sit idle)
+q = FitQueue(prob, opts)
+first, later = list(range(0, 7)), list(range(7, T))
+q.submit(cols[first], np.zeros(len(first), dtype=np.int32), U0[first], first)
+got, steps = {}, 0
+def drain(stop_at):
+    global steps
+    while q.in_system > stop_at or (stop_at == 0 and q.done > 0):
+        done, _ = q.advance()
+        if done:
+            r = q.fetch()
+            for j, tg in enumerate(r["tag"]):
+                got[int(tg)] = (r["loss"][j], r["nit"][j], r["nfev"][j], r["status"][j], r["u"][j].copy())
+        steps += 1
+        assert steps < 20000, "the queue stalled"
+drain(2)
+q.submit(cols[later], np.zeros(len(later), dtype=np.int32), U0[later], later)
+drain(0)
+q.close()
+assert sorted(got) == list(range(T))
+np.savez(sys.argv[2], loss=whole["loss"], nit=whole["nit"], nfev=whole["nfev"], u=whole["u"],
+         qloss=np.array([got[t][0] for t in range(T)]), qnit=np.array([got[t][1] for t in range(T)]),
+         qu=np.stack([got[t][4] for t in range(T)]))
+"""
+
+
+def test_batch_groups_and_the_drain_fold_do_not_change_a_fit(tmp_path):
+    """WV_GROUPS splits a problem's slots into batch groups on their own streams; when a job drains, groups are folded
+    together (fits parked, then re-admitted).  One, two and three groups must give the same fits bit for bit - from a
+    fixed task list and from a queue fed in two instalments, the second arriving after the fold - and the queue must
+    never stall."""
+    import subprocess
+    import sys
+
+    root = str(Path(__file__).resolve().parents[1])
+    script = tmp_path / "groups.py"
+    script.write_text(_GROUPS_SCRIPT)
+    outs = {}
+    for g in ("1", "2", "3"):
+        out = tmp_path / f"g{g}.npz"
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=dict(os.environ, WV_GROUPS=g),
+                       timeout=600)
+        outs[g] = np.load(out)
+    a = outs["1"]
+    np.testing.assert_array_equal(a["loss"], a["qloss"])     # instalments == fixed list
+    np.testing.assert_array_equal(a["u"][:, :a["qu"].shape[1]], a["qu"])
+    for g in ("2", "3"):
+        for key in ("loss", "nit", "nfev", "u", "qloss", "qnit", "qu"):
+            np.testing.assert_array_equal(a[key], outs[g][key], err_msg=f"WV_GROUPS={g}: {key}")
+
+
 def _random_tree(rng, depth):
     kinds = ["se", "m12", "m32", "m52", "per", "lin", "poly", "cat", "const"]
     if depth == 0 or rng.random() < 0.3:
