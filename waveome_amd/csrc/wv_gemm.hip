@@ -291,6 +291,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   // columns of the full block (32 MFMAs each): no partial sums to merge.  (ewm, ewn) = the 64 x 64 block a wave
   // works on, ecol = its first column inside that block, half = it owns 32 columns only.
   constexpr bool TRIOPT = (TAG & 4) != 0 && BN == 128 && TOUT == 0 && !SMALL;
+  // On a diagonal tile of M'M / S S' the two operand tiles are the SAME rows of the same matrix (m0 == n0, A == B, both
+  // K-strided): ONEOP loads and stages the panel once and reads both fragment kinds from it - half the global loads and
+  // LDS writes of the launch whose fixed costs weigh most (57 % MFMA-busy in round 2).  The launcher guarantees A == B.
+  constexpr bool ONEOP = TRIOPT && !A_KC && !B_KC;
   int ewm = wm, ewn = wn, ecol = 0;
   bool half = false;
   if (TRIOPT && wm != wn) {
@@ -326,12 +330,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
   kb = g.klo_mode ? ke - KC : kb;
   uint32_t offa[TA::NLOAD], offb[TB::NLOAD];
   TA::goffsets(offa, g.lda, m0, g.M, tid);
-  TB::goffsets(offb, g.ldb, n0, g.N, tid);
+  if (!ONEOP) TB::goffsets(offb, g.ldb, n0, g.N, tid);
   if (nchunk > 0) {
     TA::gload(ra, TA::chunk_base(A, g.lda, m0, kb), offa);
-    TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kb), offb);
+    if (!ONEOP) TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kb), offb);
     TA::sstore(sA[0], ra, tid);
-    TB::sstore(sB[0], rb, tid);
+    if (!ONEOP) TB::sstore(sB[0], rb, tid);
   }
   __syncthreads();
   WV_GSTAMP(1);
@@ -340,10 +344,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
     if (c + 1 < nchunk && !WV_X(4)) {
       const int kn = kb + (c + 1) * kstep;
       TA::gload(ra, TA::chunk_base(A, g.lda, m0, kn), offa);
-      TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
+      if (!ONEOP) TB::gload(rb, TB::chunk_base(B, g.ldb, n0, kn), offb);
     }
     const double* __restrict__ a_s = sA[cur];
-    const double* __restrict__ b_s = sB[cur];
+    const double* __restrict__ b_s = ONEOP ? sA[cur] : sB[cur];
     const int kc0 = kb + c * kstep;  // first k of this chunk
     if (kc0 >= wkb && kc0 < wke && !WV_X(8)) {
       if constexpr (TRIOPT) {
@@ -438,7 +442,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid) {
     }
     if (c + 1 < nchunk) {
       TA::sstore(sA[cur ^ 1], ra, tid);
-      TB::sstore(sB[cur ^ 1], rb, tid);
+      if (!ONEOP) TB::sstore(sB[cur ^ 1], rb, tid);
     }
     if (!WV_X(16)) __syncthreads();
   }
@@ -652,8 +656,9 @@ void launch_gemm(hipStream_t st, const GemmArgs& a_in, bool a_kc, bool b_kc, int
     // (only when the diagonal launch - one workgroup per tile row and matrix - can fill the GPU by itself: with few
     // fits in flight it is a serial tail of a few long tiles, 427 us of 1.19 ms at N = 4096 with one fit)
     static const int split_min = [] { const char* e = getenv("WV_TRI_SPLIT_MIN"); return e ? atoi(e) : 256; }();
+    // (a.A == a.B: both products multiply a matrix by its own transpose - the diagonal launch stages ONE operand panel)
     const bool can_split = split && a.tri == 1 && a.tri_off == 0 && a.M == a.N && a.tiles_m > 1 && a.M % BM == 0 &&
-                           a.nbatch * a.tiles_m >= split_min;
+                           a.nbatch * a.tiles_m >= split_min && a.A == a.B && a.lda == a.ldb && a.sA == a.sB;
     GemmArgs o = a;
     if (can_split) {
       o.tri = 3;

@@ -125,8 +125,9 @@ static int32_t dbg_gemm_bench_impl(wv_ctx* ctx, int32_t M, int32_t N, int32_t K,
   g.sA = (int64_t)M * K; g.sB = (int64_t)N * K; g.sC = (int64_t)M * N;
   g.lda = a_kc ? K : M; g.ldb = b_kc ? K : N; g.ldc = N;
   g.M = M; g.N = N; g.kb = 0; g.ke = K; g.alpha = 1.0; g.beta = 0.0; g.nbatch = nbatch;
-  if (mode == 1) { g.tri = 1; g.klo_mode = 1; g.tag = 1; }                   // K_y^-1 = M'M as the pipeline launches it
-  if (mode == 2) { g.tri = 1; g.beta = 1.0; g.alpha = -1e-3; g.tag = 2; }    // ... and the trailing update
+  // K_y^-1 = M'M and the trailing update as the pipeline launches them: a matrix times its own transpose (B = A)
+  if (mode == 1) { g.tri = 1; g.klo_mode = 1; g.tag = 1; g.B = g.A; g.sB = g.sA; g.ldb = g.lda; }
+  if (mode == 2) { g.tri = 1; g.beta = 1.0; g.alpha = -1e-3; g.tag = 2; g.B = g.A; g.sB = g.sA; g.ldb = g.lda; }
   if (mode == 3) { g.khi_mode = 2; }
   if (mode == 4) { g.tri = 1; }
   if (mode == 6) { g.khi_mode = 1; }
