@@ -350,6 +350,41 @@ def test_fit_trajectory_first_iterations_n2048(ctx):
     prob.close()
 
 
+def test_fit_trajectory_penalised_composite(ctx):
+    """The same iteration-by-iteration check on the PENALISED objective of a full_kernel_build-like structure (main
+    effects, a categorical, categorical x numeric products with frozen variances, Horseshoe priors on every trainable
+    kernel variance, Constant mean; N = 400): SciPy L-BFGS-B on the oracle and the device fit agree on the loss after
+    each of the first 12 iterations (1e-9 relative) and on the number of evaluations - prior value and gradient,
+    transforms and line search included."""
+    import scipy.optimize
+
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(23, 400, P=2)
+    ms = _with_priors(ModelSpec(_composite(), 4, mean_function=K.ConstantMean()), scale=1.0 / 3.0)
+    d = ms.to_dict()
+    col, iters = 1, 12
+    u0 = ms.unconstrain()
+    seen, losses = {}, []
+
+    def fun(u):
+        f, g = o.objective(d, u, X, Y[:, col])
+        seen[tuple(u)] = f
+        return f, g
+
+    ref = scipy.optimize.minimize(fun, u0, jac=True, method="L-BFGS-B", callback=lambda xk: losses.append(seen[tuple(xk)]),
+                                  options=dict(maxiter=iters, maxfun=100000, ftol=0.0, gtol=0.0))
+    assert ref.nit == iters
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    for k in range(1, iters + 1):
+        r = prob.fit([col], u0[None, :], lbfgs_opts(maxiter=k, maxfun=100000, ftol=0.0, gtol=0.0))
+        assert r["nit"][0] == k
+        assert r["loss"][0] == pytest.approx(losses[k - 1], rel=1e-9), k
+    assert r["nfev"][0] == ref.nfev
+    np.testing.assert_allclose(r["u"][0], ref.x, rtol=0, atol=1e-6)
+    prob.close()
+
+
 def _lib_codes():
     from waveome_amd import _lib
 
