@@ -136,9 +136,13 @@ def test_world_size_two_gloo_matches_single_process(tmp_path):
 def test_task_dealer_and_dynamic_map_without_a_process_group():
     from waveome_amd import parallel
 
-    d = parallel.TaskDealer(10, 4, costs=[1, 9, 1, 1, 9, 1, 1, 1, 1, 5])
+    d = parallel.TaskDealer(10, 4, costs=[1, 9, 1, 1, 9, 1, 1, 1, 1, 5], world=2)
+    # sorted by decreasing cost (stable): 1 4 9 0 2 3 5 6 7 8; three chunks, chunk j = every third task from j: each a
+    # cross-section of the job with its heaviest task first
     chunks = [d.pull().tolist() for _ in range(4)]
-    assert chunks == [[1, 4, 9, 0], [2, 3, 5, 6], [7, 8], []] and d.taken == 10   # heaviest first, stable
+    assert chunks == [[1, 0, 5, 8], [4, 2, 6, 9], [3, 7], []] and d.taken == 10
+    assert d.first_fill == 4            # max(chunk, 3/4 of the fair share of 5)
+    assert parallel.TaskDealer(3072, 32, world=8).first_fill == 288
     out = parallel.dynamic_map(7, parallel.pull_all(lambda ids: np.column_stack([ids + 0.25, -ids])), chunk=3, width=2)
     np.testing.assert_array_equal(out, np.column_stack([np.arange(7) + 0.25, -np.arange(7)]))
     st = parallel.last_map_stats()
@@ -146,4 +150,4 @@ def test_task_dealer_and_dynamic_map_without_a_process_group():
     import pytest
 
     with pytest.raises(RuntimeError):   # a run() that loses tasks it drew is an error, not a silent NaN row
-        parallel.dynamic_map(5, lambda pull: (pull()[:1], np.zeros((1, 1))), chunk=3, width=1)
+        parallel.dynamic_map(5, lambda dealer: (dealer.pull()[:1], np.zeros((1, 1))), chunk=3, width=1)

@@ -245,21 +245,26 @@ class Problem:
         U[np.arange(U.shape[1])[None, :] >= nts[:, None]] = np.nan
         return {"u": U, "loss": loss, "lml": lml, "nit": nit, "nfev": nfev, "status": st}
 
-    def fit_stream(self, pull, task_args, opts=None, width=None, backlog=None):
+    def fit_stream(self, pull, task_args, opts=None, width=None, backlog=None, first_fill=None):
         """Fit a task list that arrives in chunks, keeping the batch full across chunk boundaries: the problem's work
         queue (wv_queue_*) is topped up from `pull()` whenever fewer than `max_batch + backlog` tasks are queued or in
         flight.  `pull()` -> array of task ids (empty: nothing left; e.g. parallel.TaskDealer.pull, which deals chunks
         to the ranks of a job on demand); `task_args(ids)` -> (cols, spec_idx, U0, prior_scale or None) for those ids.
+        `first_fill` (parallel.TaskDealer.first_fill): never hold more than this many tasks - a rank of a small job must
+        not grab more than its share before anything has finished.
         Returns (ids, dict of arrays like fit_multi's) in the order the tasks were drawn.  Fits are bit-identical to
         fit / fit_multi on the same tasks (a slot's arithmetic does not depend on what else is in the batch)."""
         width = int(width or max(sp.n_trainable for sp in self.specs))
         backlog = self.max_batch // 4 if backlog is None else int(backlog)
+        hold = self.max_batch + max(0, backlog)
+        if first_fill is not None:
+            hold = max(1, min(hold, int(first_fill)))
         q = FitQueue(self, opts, width=width)
         drawn, got, spec_of = [], {}, {}
         exhausted = False
         try:
             while True:
-                while not exhausted and q.in_system < self.max_batch + max(0, backlog):
+                while not exhausted and q.in_system < hold:
                     ids = np.asarray(pull(), dtype=np.int64)
                     if len(ids) == 0:
                         exhausted = True

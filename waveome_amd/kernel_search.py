@@ -500,7 +500,7 @@ class GpuScorer:
                         f.result()
             return rec
 
-        def fit_stream(pull):
+        def fit_stream(dealer):
             """This rank's share of a step dealt in chunks (parallel.dynamic_map; candidate fits run to SciPy's
             tolerances and differ several-fold in cost): one problem holding every structure of the step, one work
             queue kept full across the chunks drawn.  A task is one candidate: its R restarts travel together."""
@@ -512,7 +512,7 @@ class GpuScorer:
             prob = self.shared.problem(self.ctx, sp_list, max(1, mb), nan_is_missing=self.nan_is_missing)
 
             def pull_fits():  # candidate ids -> fit ids (candidate * R + restart)
-                c = np.asarray(pull(), dtype=np.int64)
+                c = np.asarray(dealer.pull(), dtype=np.int64)
                 return (c[:, None] * R + np.arange(R)[None, :]).reshape(-1)
 
             def task_args(fit_ids):
@@ -526,7 +526,8 @@ class GpuScorer:
                 return np.array([tasks[i][0] for i in cand], dtype=np.int32), sidx, U0, None
 
             try:
-                fit_ids, res = prob.fit_stream(pull_fits, task_args, self.opts, width=width, backlog=mb // 4)
+                fit_ids, res = prob.fit_stream(pull_fits, task_args, self.opts, width=width, backlog=mb // 4,
+                                               first_fill=dealer.first_fill * R)
             finally:
                 prob.close()
             cand_ids = fit_ids.reshape(-1, R)[:, 0] // R
@@ -540,7 +541,7 @@ class GpuScorer:
 
         if order:
             rank, world = parallel.dist_info()
-            dyn_chunk = max(1, min(_default_batch(N) // 4, -(-len(order) // (4 * world))))
+            dyn_chunk = max(1, min(_default_batch(N) // 16, -(-len(order) // (8 * world))))
             if parallel.dist_active() and self.mode == "multi":
                 rec = parallel.dynamic_map(len(order), fit_stream, dyn_chunk, 5 + width, costs=costs)
                 self.rank_stats = parallel.last_map_stats()

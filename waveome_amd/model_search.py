@@ -187,10 +187,10 @@ class GPSearch:
         if not has_prior and np.any(pf > 0):
             raise ValueError("penalization factors must be all positive or all zero")
 
-        def fit_shard(ids, pull=None):
-            """The fits of tasks `ids` (single process / static shard), or - with `pull` - of whatever chunks this
+        def fit_shard(ids, dealer=None):
+            """The fits of tasks `ids` (single process / static shard), or - with `dealer` - of whatever chunks this
             rank draws from the job's dealer (parallel.dynamic_map); then the factor iteration on those tasks."""
-            if pull is None:
+            if dealer is None:
                 mb = max_batch or min(len(ids), _default_batch(len(Xn)))
                 prob = shared.problem(ctx, spec, max(1, mb))
                 scale = (1.0 / pf[cols[ids]]) if has_prior else None
@@ -198,8 +198,9 @@ class GPSearch:
             else:
                 mb = max_batch or min(-(-len(cols) // world) + dyn_chunk, _default_batch(len(Xn)))
                 prob = shared.problem(ctx, spec, max(1, mb))
-                ids, res = prob.fit_stream(pull, lambda t: (cols[t], None, starts[t],
-                                                            (1.0 / pf[cols[t]]) if has_prior else None), opts)
+                ids, res = prob.fit_stream(dealer.pull, lambda t: (cols[t], None, starts[t],
+                                                                   (1.0 / pf[cols[t]]) if has_prior else None),
+                                           opts, first_fill=dealer.first_fill)
             u, pf_used = res["u"], pf[cols[ids]].copy()
             # predict_y of the factor iteration is float64-only: a float32 run predicts on a float64 twin
             pprob = prob if ctx.dtype == "float64" or not iterating else Problem(float64_context(ctx), Xn, Yn, spec,
@@ -232,14 +233,14 @@ class GPSearch:
             prob.close()
             rec = np.column_stack([res["loss"], res["lml"], res["nit"] + extra[:, 0], res["nfev"] + extra[:, 1],
                                    res["status"], pf_used, u])
-            return rec if pull is None else (ids, rec)
+            return rec if dealer is None else (ids, rec)
 
         # Under torch.distributed the outputs are dealt to the ranks in chunks, on demand (these fits run to SciPy's
         # tolerances: their iteration counts differ several-fold, a static split would wait for the unluckiest rank);
         # per-rank busy times -> self.rank_stats (max / mean rank time)
-        dyn_chunk = max(1, min(_default_batch(len(Xn)) // 4, -(-len(cols) // (4 * world))))
+        dyn_chunk = max(1, min(_default_batch(len(Xn)) // 16, -(-len(cols) // (8 * world))))
         if parallel.dist_active():
-            rec = parallel.dynamic_map(len(cols), lambda pull: fit_shard(None, pull), dyn_chunk, 6 + nt)
+            rec = parallel.dynamic_map(len(cols), lambda dealer: fit_shard(None, dealer), dyn_chunk, 6 + nt)
             self.rank_stats = parallel.last_map_stats()
             if verbose and rank == 0:
                 print("rank_time_max_over_mean:", round(self.rank_stats["rank_time_max_over_mean"], 3),
@@ -352,7 +353,7 @@ class GPSearch:
         rank, world = parallel.dist_info()
         n_tasks = len(task_s)
 
-        def fit_stream(pull):
+        def fit_stream(dealer):
             # this rank's share of a job dealt in chunks (parallel.dynamic_map): one problem holding every structure,
             # one work queue kept full across the chunks it draws
             mb = max_batch or min(-(-n_tasks // world) + dyn_chunk, _default_batch(N))
@@ -366,7 +367,7 @@ class GPSearch:
                 return task_p[t].astype(np.int32), task_s[t].astype(np.int32), U0, None
 
             try:
-                ids, res = prob.fit_stream(pull, task_args, opts, width=width)
+                ids, res = prob.fit_stream(dealer.pull, task_args, opts, width=width, first_fill=dealer.first_fill)
             finally:
                 prob.close()
             out = np.full((len(ids), 5 + width), np.nan)
@@ -377,7 +378,7 @@ class GPSearch:
         # fits run to SciPy's tolerances differ several-fold in iterations (C4: 58 for Lin, 395 for Periodic per fit
         # on average, and as much again between columns): under torch.distributed the tasks are dealt to the ranks in
         # chunks, on demand, heaviest structures first (waveome/model_search.py:474-489 - Ray did this per task)
-        dyn_chunk = max(1, min(_default_batch(N) // 4, -(-n_tasks // (4 * world))))
+        dyn_chunk = max(1, min(_default_batch(N) // 16, -(-n_tasks // (8 * world))))
         if parallel.dist_active():
             rec = parallel.dynamic_map(n_tasks, fit_stream, dyn_chunk, 5 + width, costs=costs)
             self.rank_stats = parallel.last_map_stats()

@@ -274,14 +274,27 @@ class TaskDealer:
     """Hands out the task list in chunks, on demand.  Under torch.distributed the position lives in the process
     group's key-value store (`store.add` is atomic: the TCPStore torchrun already set up, no extra service), so a rank
     that finishes early simply draws the next chunk - what Ray's scheduler did for the reference, one task at a time
-    (waveome/model_search.py:474-489, 1200-1222).  `order` (default: by decreasing cost, stable) is the same on every
-    rank; without a process group the counter is local.  Every rank must create its dealers in the same sequence
-    (the key is a per-process sequence number)."""
+    (waveome/model_search.py:474-489, 1200-1222).  The sequence is the same on every rank; without a process group
+    the counter is local.  Every rank must create its dealers in the same sequence (the key is a per-process sequence
+    number).
 
-    def __init__(self, n_tasks: int, chunk: int, costs: Optional[Sequence[float]] = None):
+    What a chunk holds: the tasks are sorted by decreasing cost (stable) and chunk j takes every n_chunks-th of them
+    (j, j + n_chunks, ...), heaviest first - a CROSS-SECTION of the job.  Contiguous pieces of the sorted list would
+    hand the first ranks nothing but the most expensive structure: simulated with the measured evaluation counts of
+    the C4 job (tools/simulate_dealing.py, profiles/r03_c4_task_table.csv; 3072 tasks on 8 ranks x 512 slots) that
+    costs max / mean 1.8 where cross-sections give 1.11 and the static deal 1.14.
+    `first_fill`: how many tasks a rank may hold before any of its fits has finished - three quarters of its fair share
+    (the rest of the list goes to whoever finishes tasks first); `fit_stream` never holds more than that or
+    max_batch + backlog, whichever is smaller."""
+
+    def __init__(self, n_tasks: int, chunk: int, costs: Optional[Sequence[float]] = None, world: Optional[int] = None):
         self.n, self.chunk = int(n_tasks), max(1, int(chunk))
-        self.order = (np.arange(self.n) if costs is None
-                      else np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable"))
+        order = (np.arange(self.n) if costs is None
+                 else np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable"))
+        n_chunks = max(1, -(-self.n // self.chunk))
+        self.order = np.concatenate([order[j::n_chunks] for j in range(n_chunks)]) if self.n else order
+        world = dist_info()[1] if world is None else int(world)
+        self.first_fill = max(self.chunk, int(np.ceil(0.75 * self.n / max(1, world))))
         self.taken = 0          # tasks this rank drew
         self._local = 0
         self._store = None
@@ -360,21 +373,22 @@ def gather_objects(obj, device=None) -> list:
     return [pickle.loads(b.cpu().numpy()[:int(v.item())].tobytes()) for b, v in zip(bufs, sizes)]
 
 
-def dynamic_map(n_tasks: int, run: Callable[[Callable[[], np.ndarray]], tuple], chunk: int, width: int,
+def dynamic_map(n_tasks: int, run: Callable[["TaskDealer"], tuple], chunk: int, width: int,
                 costs=None, device=None) -> np.ndarray:
     """Dynamic counterpart of `sharded_map` for jobs whose tasks differ in cost in ways nobody knows beforehand
-    (fits run to SciPy's tolerances: 58 ... 395 iterations per fit in BASELINE config C4).
+    (fits run to SciPy's tolerances: 58 ... 395 iterations per fit in BASELINE config C4, and as much again between
+    columns).
 
-    `run(pull)` does this rank's work: it calls `pull()` whenever it can take more tasks (an empty array = none
-    left), and returns (task ids, [len, width] records) for everything it drew.  Chunks are dealt heaviest first
-    (by `costs`) from a shared counter, so the ranks finish within about one chunk's work of each other; results do
-    not depend on who fitted what (a fit depends only on its task), so the gathered table is bit-identical to a
-    single-process run.  Per-rank busy times -> `last_map_stats()`."""
+    `run(dealer)` does this rank's work: it calls `dealer.pull()` whenever it can take more tasks (an empty array =
+    none left; `dealer.first_fill` bounds what it should hold before any of its tasks has finished), and returns (task
+    ids, [len, width] records) for everything it drew.  Results do not depend on who fitted what (a fit depends only
+    on its task), so the gathered table is bit-identical to a single-process run.  Per-rank busy times ->
+    `last_map_stats()`."""
     import time
 
     dealer = TaskDealer(n_tasks, chunk, costs)
     t0 = time.perf_counter()
-    ids, rec = run(dealer.pull)
+    ids, rec = run(dealer)
     busy = time.perf_counter() - t0
     ids = np.asarray(ids, dtype=np.int64)
     if len(ids) != dealer.taken:
@@ -387,10 +401,10 @@ def dynamic_map(n_tasks: int, run: Callable[[Callable[[], np.ndarray]], tuple], 
 def pull_all(fn: Callable[[np.ndarray], np.ndarray]) -> Callable:
     """Adapter: a `run` for dynamic_map out of a plain fn(ids) -> records, one call per chunk (CPU-side work; GPU
     fits use `engine.Problem.fit_stream`, which keeps one batch full across chunks)."""
-    def run(pull):
+    def run(dealer):
         all_ids, recs = [], []
         while True:
-            ids = pull()
+            ids = dealer.pull()
             if len(ids) == 0:
                 break
             all_ids.append(np.asarray(ids))
