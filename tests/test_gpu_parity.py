@@ -774,6 +774,22 @@ def test_results_do_not_depend_on_batch_composition(ctx):
     fit_small = small.fit(cols, U, lbfgs_opts(maxiter=25))
     np.testing.assert_array_equal(fit_big["u"], fit_small["u"])
     np.testing.assert_array_equal(fit_big["loss"], fit_small["loss"])
+    # ... and across the few-fits threshold (more than 8 fits in flight switch the Gram / trace passes to several tiles
+    # per workgroup): 16 tasks in one launch against the same tasks one at a time.  Round 3 found the gradient's last
+    # bits depending on that (per-workgroup partial sums of 4 tiles vs 1) - and with them, after a few hundred
+    # chaotic iterations, which optimum a fit of a multi-rank job reported; the trace pass now writes one partial per
+    # TILE in every regime and the reduction walks them in one fixed order.
+    cols16 = (np.arange(16) % 6).astype(np.int32)
+    U16 = np.stack([ms.unconstrain() + 0.1 * rng.normal(size=ms.n_trainable) for _ in range(16)])
+    l16, g16, _ = big.value_grad(cols16, U16)
+    for t in (0, 7, 15):
+        l1, g1, _ = small.value_grad(cols16[t:t + 1], U16[t:t + 1])
+        assert l1[0] == l16[t]
+        np.testing.assert_array_equal(g1[0], g16[t])
+    fit16 = big.fit(cols16, U16, lbfgs_opts(maxiter=40))
+    fit1 = small.fit(cols16, U16, lbfgs_opts(maxiter=40))
+    np.testing.assert_array_equal(fit16["u"], fit1["u"])
+    np.testing.assert_array_equal(fit16["nfev"], fit1["nfev"])
     big.close()
     small.close()
 

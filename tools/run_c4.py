@@ -26,5 +26,6 @@ dt = time.perf_counter() - t0
 print(f"C4 shape: {P} outputs x 6 structures = {len(tab)} fits in {dt:.1f} s -> {len(tab)/dt:.1f} fits/s; "
       f"mean iterations {tab['nit'].mean():.1f}, evaluations {tab['nfev'].mean():.1f}; status counts {tab['status'].value_counts().to_dict()}")
 print(tab.groupby('structure')[['bic','nit']].mean())
+print(f"table checksum {float(np.nansum(tab['loss'].to_numpy() * np.arange(1, len(tab) + 1))):.10f}")  # (tools/run_c4_ranks.py prints the same)
 if os.environ.get("WV_C4_TABLE"):   # per-task evaluation counts, e.g. for tools/simulate_dealing.py
     tab.reset_index()[["output", "structure", "nit", "nfev"]].to_csv(os.environ["WV_C4_TABLE"], index=False)

@@ -314,7 +314,7 @@ void wv_problem_destroy(wv_problem* h) {
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
                   p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.dspans, p.dspec_span, p.dmask,
                   p.dnobs, p.Kbuf32, p.Mbuf32, p.MTbuf32,
-                  p.Pbuf32};
+                  p.Pbuf32, p.dquad};
   for (void* q : ptrs)
     if (q) hipFree(q);
   delete h;
@@ -557,6 +557,19 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     WV_HIP_TRY(hipHostMalloc((void**)&g.h_status, sizeof(int32_t) * g.nslots));
     WV_HIP_TRY(hipHostMalloc((void**)&g.h_spec, sizeof(int32_t) * g.nslots));
     std::memset(g.h_spec, 0, sizeof(int32_t) * g.nslots);
+  }
+  {
+    // per-quad gradient accumulators of the few-fits regime (wv_gram.hip, trace_group_kernel): optional - without the
+    // buffer few fits are traced like many (four tiles per workgroup), same numbers, a little more latency
+    p.quad_stride = 64 * (int64_t)std::max(1, p.max_red);
+    p.quad_fits = std::min(FEW_FITS, base + (extra ? 1 : 0));
+    const size_t bytes = sizeof(double) * (size_t)ng * p.quad_fits * p.ntiles() * p.quad_stride;
+    if (bytes > ((size_t)8 << 30) || hipMalloc((void**)&p.dquad, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      p.dquad = nullptr;
+    } else {
+      p.workspace_bytes += (int64_t)bytes;
+    }
   }
   *out = h.release();
   return WV_OK;

@@ -29,6 +29,7 @@ constexpr int NB = 64;          // diagonal block / panel width
 constexpr int GT = 64;          // Gram / trace tile edge
 constexpr int MAX_FEAT = 64;    // feature slots per side staged in LDS by the Gram kernels
 constexpr int MAX_TERM_F = 4;   // factors per term
+constexpr int FEW_FITS = 8;     // at most this many fits in a launch: Gram / trace passes run ONE tile per workgroup
 
 // ---- device-side spec --------------------------------------------------------------
 struct DevFactor {
@@ -189,6 +190,11 @@ struct Problem {
   double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
   double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials
+  // few fits in flight (<= FEW_FITS): per-quad gradient accumulators of every tile, [groups][quad_fits][ntiles][quad_stride],
+  // summed by trace_group_kernel in the order of the many-fits regime (null: that regime is used for few fits too)
+  double *dquad = nullptr;
+  int64_t quad_stride = 0;
+  int quad_fits = 0;
   double *dout = nullptr;      // [max_batch][out_stride]
   int32_t *dcol = nullptr, *dstatus = nullptr;
   int64_t workspace_bytes = 0;

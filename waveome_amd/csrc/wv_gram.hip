@@ -469,7 +469,7 @@ __device__ inline bool tile_is_zero(const int32_t* __restrict__ span, int ti, in
 }
 
 constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged once per workgroup) ...
-constexpr int FEW_FITS = 8;  // ... but ONE with at most this many fits in flight: more, shorter workgroups (latency regime)
+// ... but ONE with at most FEW_FITS (wv_device.hpp) fits in flight: more, shorter workgroups (latency regime)
 
 // MASKED: missing outputs (row masks per output column), see trace_kernel.  MULTI = false: every factor of every
 // structure of the problem acts on ONE column (what full_kernel_build produces) - fewer live registers, more waves.
@@ -633,7 +633,11 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // 7.4 per 512 fits - measured in round 3 and not kept.)
 // PROD = false: no structure of the problem has a product term (sums of single factors - the headline, C2, C5 and most
 // kernel-search candidates): the 4 x 4 copy of the weights that products need is not instantiated.
-template <typename R, bool MULTI, bool MASKED, bool PROD = true, bool W4 = false>
+// QUADOUT (few fits in flight: one tile per workgroup): the workgroup leaves its per-quad accumulators red[slot][64] in
+// `quad` instead of reducing them - trace_group_kernel then adds the tiles of every group of TRACE_TPW in the order a
+// TRACE_TPW-tile workgroup would have, so that a gradient's reduction tree - and with it a fit's whole trajectory -
+// does not depend on how many fits share the launch.
+template <typename R, bool MULTI, bool MASKED, bool PROD = true, bool W4 = false, bool QUADOUT = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ F, const double* __restrict__ FC,
@@ -645,7 +649,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
                                                     int tpw, int part_stride, const int32_t* __restrict__ spans,
                                                     const int32_t* __restrict__ spec_span,
                                                     const int32_t* __restrict__ col,
-                                                    const uint8_t* __restrict__ mask) {
+                                                    const uint8_t* __restrict__ mask,
+                                                    double* __restrict__ quad_out = nullptr, int quad_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -732,6 +737,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
     }
   }
   __syncthreads();
+  if constexpr (QUADOUT) {  // (tpw == 1: this workgroup's tile is blockIdx.x; a skipped zero tile leaves zeros)
+    double* q = quad_out + ((int64_t)blockIdx.y * ntiles + blockIdx.x) * quad_stride;
+    for (int i = tid; i < nred * 64; i += 256) q[i] = red[i];
+    return;
+  }
   // one 64-lane reduction per slot (wave w takes slots w, w + 4, ...); the total goes back into red[slot * 64]
   for (int sidx = wave; sidx < nred; sidx += 4) {
     const double v = wave_sum(red[sidx * 64 + lane]);
@@ -749,6 +759,43 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
   if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[(nred - 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
   double* out = part + ((int64_t)b * part_stride + blockIdx.x) * np;
+  for (int p = tid; p < np; p += 256) out[p] = pacc[p];
+}
+
+// Few fits in flight: the tiles were traced one per workgroup (trace_kernel<..., QUADOUT>); group g adds the per-quad
+// accumulators of tiles TRACE_TPW g ... in tile order - exactly what one workgroup walking those tiles does with its LDS
+// accumulators - then reduces over the 64 quads and maps slots to parameters like the tail of trace_kernel, and writes
+// the record part[b][g] that a TRACE_TPW-tile workgroup would have written.
+__global__ __launch_bounds__(256) void trace_group_kernel(const DevSpec* __restrict__ specs,
+                                                          const int32_t* __restrict__ slot_spec,
+                                                          const double* __restrict__ quad, double* __restrict__ part,
+                                                          int slot0, int ntiles, int quad_stride, int part_stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = slot0 + blockIdx.y, g = blockIdx.x;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+  const int np = sp->n_params, nred = sp->n_red;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* red = smem;          // [nred] totals
+  double* pacc = smem + nred;  // [np]
+  for (int q = tid; q < np; q += 256) pacc[q] = 0.0;
+  const int t0 = g * TRACE_TPW, t1 = min(ntiles, t0 + TRACE_TPW);
+  for (int sidx = wave; sidx < nred; sidx += 4) {
+    double a = 0.0;
+    for (int t = t0; t < t1; ++t) a += quad[((int64_t)blockIdx.y * ntiles + t) * quad_stride + sidx * 64 + lane];
+    const double v = wave_sum(a);
+    if (lane == 0) red[sidx] = v;
+  }
+  __syncthreads();
+  for (int f = tid; f < sp->n_factors; f += 256) {
+    const DevFactor ff = sp->factors[f];
+    if (ff.sbase < 0) continue;
+    for (int m = 0; m < ff.nsum; ++m)
+      if (ff.trainable & (1 << m))
+        __hip_atomic_fetch_add(&pacc[ff.p[m]], red[ff.sbase + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[nred - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  double* out = part + ((int64_t)b * part_stride + g) * np;
   for (int p = tid; p < np; p += 256) out[p] = pacc[p];
 }
 
@@ -807,50 +854,53 @@ void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper)
 
 // Workgroups per fit of the trace pass over nb fits (= partial-sum records per fit that the reduce pass adds up); a
 // fit's records start at slot * trace_part_stride(p) whatever nb is, so groups of different size never overlap.
-int trace_nwg(const Problem& p, int nb) {
-  const int tpw = nb <= FEW_FITS ? 1 : TRACE_TPW;
-  return (p.ntiles() + tpw - 1) / tpw;
-}
+int trace_nwg(const Problem& p, int /*nb*/) { return (p.ntiles() + TRACE_TPW - 1) / TRACE_TPW; }  // records per fit: one
+// per group of TRACE_TPW tiles in every regime (written by the workgroup that walked them, or by trace_group_kernel)
 int trace_part_stride(const Problem& p) { return p.ntiles(); }
 
+template <typename RT, bool MU, bool MA, bool PROD, bool W4>
+static void trace_launch(Problem& p, hipStream_t st, const RT* kbuf, int slot0, int nb) {
+  // few fits in flight: one tile per workgroup, per-quad accumulators to p.dquad, groups summed by trace_group_kernel
+  double* quad = nullptr;
+  if (nb <= FEW_FITS && nb <= p.quad_fits && p.dquad)
+    for (size_t gi = 0; gi < p.groups.size(); ++gi)
+      if (p.groups[gi].slot0 == slot0) quad = p.dquad + (int64_t)gi * p.quad_fits * p.ntiles() * p.quad_stride;
+  const size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
+  const dim3 blk(256);
+  if (quad) {
+    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, true>>()) return;
+    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, true>), dim3(p.ntiles(), nb), blk, sh, st, p.dspec, p.dslotspec,
+                       p.dfeat, p.dfconst, p.dtheta, kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0,
+                       p.ntiles(), 1, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol,
+                       p.dmask, quad, (int)p.quad_stride);
+    hipLaunchKernelGGL(trace_group_kernel, dim3(trace_nwg(p, nb), nb), blk, sizeof(double) * (p.max_red + p.np_stride), st,
+                       p.dspec, p.dslotspec, quad, p.dpart, slot0, p.ntiles(), (int)p.quad_stride, trace_part_stride(p));
+  } else {
+    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, false>>()) return;
+    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, false>), dim3(trace_nwg(p, nb), nb), blk, sh, st, p.dspec,
+                       p.dslotspec, p.dfeat, p.dfconst, p.dtheta, kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact,
+                       slot0, p.ntiles(), TRACE_TPW, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr,
+                       p.dspec_span, p.dcol, p.dmask, nullptr, 0);
+  }
+}
+
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
-  const int tpw = nb <= FEW_FITS ? 1 : TRACE_TPW;
-  dim3 grid(trace_nwg(p, nb), nb), blk(256);
-  size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   p.timer.begin(st, ST_TRACE);
-#define WV_TRACE_LAUNCH_M(RT, MU, MA, KBUF)                                                                        \
-  if (exp_table_ok<trace_kernel<RT, MU, MA>>())                                                                     \
-  hipLaunchKernelGGL((trace_kernel<RT, MU, MA>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, KBUF, \
-                     p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, trace_part_stride(p), \
-                     p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
-#define WV_TRACE_LAUNCH(RT, MU, KBUF)              \
-  do {                                             \
-    if (p.dmask) { WV_TRACE_LAUNCH_M(RT, MU, true, KBUF); } \
-    else { WV_TRACE_LAUNCH_M(RT, MU, false, KBUF); }   \
-  } while (0)
   static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   // (512 fits at N = 2048, same box: general kernel 7.4 ms; without the product paths 7.03 at 3 waves per SIMD - 140
   // VGPRs, nothing spilled - and 6.68 at 4 waves - 128 VGPRs, 10 spilled; WV_TRACE_WAVES=3 selects the former)
   static const int waves = [] { const char* e = getenv("WV_TRACE_WAVES"); return e ? atoi(e) : 4; }();
   if (!p.f32 && !multi && !p.any_product && !p.dmask) {  // sums of single-column factors, float64, no missing outputs
-#define WV_TRACE_SUM(W4)                                                                                              \
-  if (exp_table_ok<trace_kernel<double, false, false, false, W4>>())                                                   \
-  hipLaunchKernelGGL((trace_kernel<double, false, false, false, W4>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, \
-                     p.dfconst, p.dtheta, p.Kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0,        \
-                     p.ntiles(), tpw, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol,  \
-                     p.dmask)
-    if (waves == 4) { WV_TRACE_SUM(true); } else { WV_TRACE_SUM(false); }
-#undef WV_TRACE_SUM
+    if (waves == 4) trace_launch<double, false, false, false, true>(p, st, p.Kbuf, slot0, nb);
+    else trace_launch<double, false, false, false, false>(p, st, p.Kbuf, slot0, nb);
   } else if (p.f32) {
-    if (multi) WV_TRACE_LAUNCH(float, true, p.Kbuf32);
-    else WV_TRACE_LAUNCH(float, false, p.Kbuf32);
+    if (multi) { if (p.dmask) trace_launch<float, true, true, true, false>(p, st, p.Kbuf32, slot0, nb); else trace_launch<float, true, false, true, false>(p, st, p.Kbuf32, slot0, nb); }
+    else { if (p.dmask) trace_launch<float, false, true, true, false>(p, st, p.Kbuf32, slot0, nb); else trace_launch<float, false, false, true, false>(p, st, p.Kbuf32, slot0, nb); }
   } else {
-    if (multi) WV_TRACE_LAUNCH(double, true, p.Kbuf);
-    else WV_TRACE_LAUNCH(double, false, p.Kbuf);
+    if (multi) { if (p.dmask) trace_launch<double, true, true, true, false>(p, st, p.Kbuf, slot0, nb); else trace_launch<double, true, false, true, false>(p, st, p.Kbuf, slot0, nb); }
+    else { if (p.dmask) trace_launch<double, false, true, true, false>(p, st, p.Kbuf, slot0, nb); else trace_launch<double, false, false, true, false>(p, st, p.Kbuf, slot0, nb); }
   }
-#undef WV_TRACE_LAUNCH
-#undef WV_TRACE_LAUNCH_M
   p.timer.end(st);
   p.timer.work(ST_TRACE, 0.0, (double)nb * (p.f32 ? 4.0 : 8.0) * ((double)p.Npad * (p.Npad + GT) / 2.0 + (double)p.N * p.D));
 }
