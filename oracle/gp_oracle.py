@@ -281,6 +281,8 @@ def lml(spec, theta, X, y):
     N = X.shape[0]
     Ky = gram(spec, theta, X)
     Ky[np.diag_indices(N)] += theta[spec["noise"]]
+    if not np.all(np.isfinite(Ky)):
+        raise np.linalg.LinAlgError("non-finite Gram matrix")
     L = np.linalg.cholesky(Ky)
     z = scipy.linalg.solve_triangular(L, _resid(spec, theta, y), lower=True)
     return float(-0.5 * z @ z - np.sum(np.log(np.diag(L))) - 0.5 * N * LOG_2PI)
@@ -302,6 +304,8 @@ def lml_and_grad(spec, theta, X, y):
         prod = vals[0][0] if len(vals) == 1 else np.prod([k for k, _ in vals], axis=0)
         Ky += prod
     Ky[np.diag_indices(N)] += theta[spec["noise"]]
+    if not np.all(np.isfinite(Ky)):  # (a lengthscale driven to 0 by a long trial step: 0/0) - same outcome as "not
+        raise np.linalg.LinAlgError("non-finite Gram matrix")  # positive definite": objective() reports +inf
     L = np.linalg.cholesky(Ky)
     r = _resid(spec, theta, y)
     z = scipy.linalg.solve_triangular(L, r, lower=True)
@@ -429,11 +433,18 @@ def fit(spec, X, y, maxiter=50000, maxfun=None, ftol=2.220446049250313e-09, gtol
                  "maxcor": maxcor, "maxls": maxls},
     )
     theta = unpack_u(spec, res.x)
+    try:
+        end_lml = lml(spec, theta, X, y)
+    except np.linalg.LinAlgError:
+        # SciPy's line search does not recover from a +inf trial value (its interpolation turns the iterate into
+        # NaN); the reference's TensorFlow Cholesky raises there and waveome retries from random parameters
+        # (model_classes.py:323-340).  The checker reports such a fit as failed: no finite score.
+        end_lml = -np.inf
     return {
         "theta": theta,
         "u": res.x,
-        "loss": float(res.fun),
-        "lml": lml(spec, theta, X, y),
+        "loss": float(res.fun) if np.isfinite(end_lml) else np.inf,
+        "lml": end_lml,
         "nit": int(res.nit),
         "nfev": int(res.nfev),
         "status": int(res.status),

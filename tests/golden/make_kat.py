@@ -10,6 +10,14 @@ literals; expected values are the numbers printed in the stored cell outputs:
 * KAT-5  kernel_learning/gpflow_basic_colab.ipynb cells 4 (commented kernel line
          `gpflow.kernels.Periodic(gpflow.kernels.SquaredExponential())`) and 7 (comment "# Per = -12.242"): the
          KAT-1 data fitted with the Periodic kernel from the GPflow defaults, Scipy().minimize(maxiter=100)
+* KAT-6  examples/simulations/simple_regression_different_models.ipynb cells 1-5, 7: BaseGP (an SVGP with Z = X,
+         Gaussian likelihood, Constant mean) with a SquaredExponential kernel on seeded N = 100 data; stored: two
+         fitted parameter tables at full precision, the training losses next to them and
+         "BIC: -134.44134538865075" = 2 * 6 - 2 * ELBO of the second one (waveome/utilities.py:94-95,
+         model_classes.py:575-582: k = 6 Parameter objects)
+* KAT-7  examples/simulations/penalized_regression.ipynb cells 1, 3, 4: GPSearch(...).run_search(random_seed=1) on seeded
+         N = 100 data with a 50-level unit column; stored: the best model 'categorical[4]+squared_exponential[0]'
+         with its parameters at full precision and 'bic': 245.35 - a SURVIVING Categorical variance
 * KAT-4  waveome_overview.ipynb cells 4, 8, 9, 10, 11, 13: the end-to-end penalised run
          (GPSearch(...).penalized_optimization(random_seed=9102, kerns=[SE, Lin()])) on 100 people x 5
          observations; stored: the first rows of the data frame (checked below), the fitted `outcome1`
@@ -68,6 +76,75 @@ out = {
                           "theta": [0.9586300813658013, 0.10091476512813762, 0.5662223046516239,
                                     1.0418485608615156e-06]},
     },
+}
+# ---- KAT-6: simple_regression_different_models.ipynb cell 1, statement for statement ----
+np.random.seed(9102)
+N6 = 100
+X6 = np.random.uniform(low=-5, high=5, size=(N6, 1))
+Y6 = np.sin(X6)
+Y6[X6 >= 3] = 0.5
+Y6 += np.random.normal(scale=.1, size=(N6, 1))
+assert f"{X6[0, 0]:.5f}" == "-4.02011"   # cell 2 prints inducing_variable.Z = [[-4.02011...
+out["kat6"] = {
+    "source": "examples/simulations/simple_regression_different_models.ipynb cells 1 (data), 2-5 (fits), 7 (BIC)",
+    "model": "model_classes.BaseGP(X, Y, kernel=SquaredExponential()): SVGP, Z = X (100 points), Gaussian likelihood, "
+             "Constant mean; randomize_params + optimize_params (Adam / natural gradients, stopped on its own "
+             "convergence rule), then random_restart_optimize(3)",
+    "X": X6[:, 0].tolist(), "Y": Y6[:, 0].tolist(), "kernel": "se",
+    # what the stored numbers are: the ELBO of an SVGP whose q had NOT fully converged (at the stored theta the
+    # collapsed bound with GPflow's 1e-6 jitter is 73.2288, the exact LML 73.2301), so they bound, softly:
+    # stored ELBO <= LML(stored theta) <= max LML
+    "expected": {
+        "first_fit": {"mean_function.c": 0.32965214640943175, "kernel.variance": 0.24707589611807843,
+                      "kernel.lengthscales": 1.37048, "likelihood.variance": 0.00846385650648054,
+                      "training_loss_round_1500": -72.4484598846995},          # cell 3
+        "after_restarts": {"mean_function.c": 0.4093631338560377, "kernel.variance": 0.39237571168426433,
+                           "kernel.lengthscales": 1.37526, "likelihood.variance": 0.008144713086723682,
+                           "training_loss_round_1000": -73.22063598606498,    # cell 4, restart 3
+                           "bic": -134.44134538865075,                          # cell 7
+                           "variance_explained": [0.392, 0.008]},               # cell 7
+        "n_parameter_objects": 6,
+    },
+    # not from the reference: this repo's oracle at those points and from the defaults (drift guard)
+    "oracle_record": {"lml_at_first_fit": 72.47432991617235, "lml_after_restarts": 73.23009808812573,
+                      "lml_optimum": 73.27256449239444},
+}
+# ---- KAT-7: penalized_regression.ipynb cell 1, statement for statement ----
+np.random.seed(1)
+N7 = 100
+num_covariates = 5
+num_ids = 50
+X7 = np.random.uniform(low=-5, high=5, size=(N7, num_covariates - 1)).reshape(-1, num_covariates - 1)
+X7 = np.hstack((X7, np.random.choice(a=np.arange(num_ids), size=(N7, 1)).astype(int)))
+Y7 = (
+    np.sin(X7[:, 0])
+    + ((2 / num_ids) * X7[:, num_covariates - 1] - 1)
+    + np.random.uniform(low=-1, high=1, size=N7)
+).reshape(-1, 1)
+# cell 1 prints np.round(X[:5, :], 1)
+assert np.round(X7[:5, :], 1).tolist() == [[-0.8, 2.2, -5.0, -2.0, 7.0], [-3.5, -4.1, -3.1, -1.5, 48.0],
+                                           [-1.0, 0.4, -0.8, 1.9, 28.0], [-3.0, 3.8, -4.7, 1.7, 19.0],
+                                           [-0.8, 0.6, -3.6, -3.0, 27.0]]
+out["kat7"] = {
+    "source": "examples/simulations/penalized_regression.ipynb cells 1 (data), 3 (call), 4 (stored best model)",
+    "call": "GPSearch(X=DataFrame(X, columns=X0..X4), Y=DataFrame(Y, columns=[Y]), unit_col='X4', "
+            "categorical_vars=['X4']).run_search(random_seed=1)",
+    "X": X7.tolist(), "Y": Y7[:, 0].tolist(),
+    "expected": {
+        "best_model": "categorical[4]+squared_exponential[0]",
+        "kernel.kernels[0].variance": 0.28643070507034357,        # Categorical[X4]: a surviving unit effect
+        "kernel.kernels[1].variance": 0.4834780359781155,         # SquaredExponential[X0]
+        "kernel.kernels[1].lengthscales": 0.3019104442741199,
+        "likelihood.variance": 0.2901947957045917,
+        "mean_function.c": -0.05754963,
+        "bic": 245.35,                                             # round(2 * 7 - 2 * log posterior, 2)
+        "n_parameter_objects": 7,
+        "Z_row0": [-2.63185406e-01, 6.68667791e-01, -1.53657],    # as printed (the third to the table's 6 s.f.)
+    },
+    # not from the reference: this repo's oracle on the preprocessed data (X0..X3 and Y standardised with ddof = 1, X4
+    # factorised): LML at the stored point, and the stationary point L-BFGS-B reaches FROM it (5 iterations)
+    "oracle_record": {"lml_at_stored": -115.68174802182943, "lml_nearby_optimum": -115.67340000936113,
+                      "theta_nearby_optimum": [0.28646377, 0.4835263, 0.30193007, 0.29019125, -0.01581984]},
 }
 # ---- KAT-4: waveome_overview.ipynb cell 4, statement for statement (legacy NumPy RNG; note the sort) ----
 import pandas as pd

@@ -313,6 +313,48 @@ def test_kat5_periodic_known_answer_through_gpu(ctx, golden_dir):
     prob.close()
 
 
+def test_kat6_constant_mean_se_through_the_model_class(ctx, golden_dir):
+    """KAT-6 (simple_regression_different_models.ipynb cells 1-5, 7): the reference's BaseGP - an SVGP with Z = X,
+    Constant mean, SquaredExponential - stores two full-precision parameter tables, the ELBO each had reached and
+    'BIC: -134.44134538865075'.  Through the model class on the GPU: the exact LML at the stored parameters sits just
+    above the stored ELBO (the SVGP's q had not fully converged: bounds, 1e-4 relative), calc_metric's rule
+    (2 k - 2 log posterior, k counting q_mu and q_sqrt) reproduces the printed BIC to 0.02, and the fit from the
+    stored point ends at the optimum the oracle finds, a little higher."""
+    from waveome_amd.model_classes import PSVGP
+
+    with open(os.path.join(golden_dir, "kat.json")) as fh:
+        c = json.load(fh)["kat6"]
+    X = np.array(c["X"]).reshape(-1, 1)
+    Y = np.array(c["Y"]).reshape(-1, 1)
+    exp, rec = c["expected"], c["oracle_record"]
+    m = PSVGP(X, Y, kernel=K.SquaredExponential(active_dims=[0]), context=ctx,
+              penalized_options={"penalization_factor": 0.0})          # BaseGP: no prior
+    assert len(m.trainable_parameters) + 2 == exp["n_parameter_objects"]
+
+    def put(e):
+        m.kernel.variance.assign(e["kernel.variance"])
+        m.kernel.lengthscales.assign(e["kernel.lengthscales"])
+        m.likelihood.variance.assign(e["likelihood.variance"])
+        m.mean_function.c.assign(e["mean_function.c"])
+
+    put(exp["first_fit"])
+    l1 = m.maximum_log_likelihood_objective()
+    assert l1 == pytest.approx(rec["lml_at_first_fit"], rel=1e-10)
+    assert 0.0 <= l1 + exp["first_fit"]["training_loss_round_1500"] <= 0.03
+    put(exp["after_restarts"])
+    l2 = m.maximum_log_likelihood_objective()
+    assert l2 == pytest.approx(rec["lml_after_restarts"], rel=1e-10)
+    elbo2 = (2 * exp["n_parameter_objects"] - exp["after_restarts"]["bic"]) / 2
+    assert 0.0 <= l2 - elbo2 <= 0.012
+    assert abs(m.calc_metric() - exp["after_restarts"]["bic"]) <= 0.02
+    assert [round(float(m.kernel.variance.value), 3), round(float(m.likelihood.variance.value), 3)] == \
+        exp["after_restarts"]["variance_explained"]
+    m.optimize_params()
+    l3 = m.maximum_log_likelihood_objective()
+    assert l3 == pytest.approx(rec["lml_optimum"], abs=1e-5)
+    assert 0.0 <= l3 - l2 <= 0.06
+
+
 def test_fit_trajectory_first_iterations_n2048(ctx):
     """Fit-level parity at the headline size: SciPy L-BFGS-B on the oracle objective (what
     waveome/model_classes.py:325-334 runs) and the device fit take the same first 10 iterations on a bench column -
