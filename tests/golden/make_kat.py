@@ -18,6 +18,10 @@ literals; expected values are the numbers printed in the stored cell outputs:
 * KAT-7  examples/simulations/penalized_regression.ipynb cells 1, 3, 4: GPSearch(...).run_search(random_seed=1) on seeded
          N = 100 data with a 50-level unit column; stored: the best model 'categorical[4]+squared_exponential[0]'
          with its parameters at full precision and 'bic': 245.35 - a SURVIVING Categorical variance
+* KAT-8  kernel_learning/data_generation.ipynb cells 3, 6, 9, 10, 14: the notebook writes simulated_data.csv (held by the
+         reference next to it) and then evaluates, with scipy.stats.multivariate_normal, the log-likelihood of its
+         y1_obs column under the generating kernel Matern12(1, 1)[time] + Categorical(2)[unit] + 0.01 I - stored as
+         k1_bic = 3 ln 126 - 2 loglik = 169.71614261744028.  A VALUE at fixed parameters: no optimiser in between.
 * KAT-4  waveome_overview.ipynb cells 4, 8, 9, 10, 11, 13: the end-to-end penalised run
          (GPSearch(...).penalized_optimization(random_seed=9102, kerns=[SE, Lin()])) on 100 people x 5
          observations; stored: the first rows of the data frame (checked below), the fitted `outcome1`
@@ -29,6 +33,7 @@ import json
 import os
 
 import numpy as np
+import pandas as pd
 
 np.random.seed(9102)
 X1 = np.random.uniform(low=0, high=10, size=10)
@@ -46,6 +51,9 @@ out = {
         "expected": {"variance": 0.749872, "lengthscales": 0.740194, "noise": 0.0379764,
                      "lml": -9.914289155637},
         "printed_sig_figs": 6,
+        # cell 13 prints m.trainable_parameters at full precision (lengthscales, variance, noise)
+        "expected_full": {"variance": 0.7498722077802612, "lengthscales": 0.7401937019825038,
+                          "noise": 0.03797644835355126},
     },
     "kat2": {
         "source": "kernel_learning/gpflow_basic.ipynb cells 28-31",
@@ -145,6 +153,36 @@ out["kat7"] = {
     # factorised): LML at the stored point, and the stationary point L-BFGS-B reaches FROM it (5 iterations)
     "oracle_record": {"lml_at_stored": -115.68174802182943, "lml_nearby_optimum": -115.67340000936113,
                       "theta_nearby_optimum": [0.28646377, 0.4835263, 0.30193007, 0.29019125, -0.01581984]},
+}
+# ---- KAT-8: data_generation.ipynb.  The inputs regenerate from the notebook's seed (cell 3); y1_obs is a draw through
+# TensorFlow kernels and np.random.multivariate_normal's SVD, rounded to 2 dp and written to simulated_data.csv
+# (cells 7, 9, 10) - that column is read from the data file the reference holds (data, not code) when it is there.
+np.random.seed(9012)
+num_units = 10
+treat_group = np.random.binomial(n=1, p=0.5, size=num_units)
+num_obs = np.random.poisson(lam=12, size=num_units)
+x8 = np.concatenate([np.sort(np.round(np.random.uniform(low=0, high=12, size=i), 1)) for i in num_obs], axis=0)
+df8 = np.array([np.repeat(np.arange(num_units), num_obs), np.repeat(treat_group, num_obs), x8]).T
+assert df8.shape == (126, 3) and df8[:5, 2].tolist() == [0.0, 1.4, 2.0, 2.4, 3.4]       # cell 3's printed output
+_csv = "/root/reference/kernel_learning/simulated_data.csv"
+_here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat.json")
+if os.path.exists(_csv):
+    d8 = pd.read_csv(_csv)
+    assert np.array_equal(d8[["unit", "treatment", "time"]].to_numpy(float), df8)          # the file IS that run's output
+    assert d8.loc[:1, ["y1_obs", "y2_obs", "y3_obs", "y4_obs"]].to_numpy().tolist() == \
+        [[1.51, -2.29, -0.27, 3.07], [1.35, -2.21, -0.43, 2.83]]                            # cell 9's printed head
+    y8 = d8["y1_obs"].tolist()
+else:  # regenerating away from the reference tree: keep the column already in the fixture
+    with open(_here) as fh:
+        y8 = json.load(fh)["kat8"]["y1_obs"]
+out["kat8"] = {
+    "source": "kernel_learning/data_generation.ipynb cells 3 (inputs), 6 (k1), 9-10 (simulated_data.csv), 14 (k1_bic)",
+    "model": "scipy.stats.multivariate_normal(mean=0, cov=k1(X) + 1e-2 I).logpdf(y1_obs), "
+             "k1 = Matern12(variance=1, lengthscales=1, active_dims=[2]) + Categorical(variance=2, active_dims=[0]); "
+             "calc_bic = k ln n - 2 loglik with k = len(k1.trainable_parameters) = 3 (helper_functions.py)",
+    "unit": df8[:, 0].tolist(), "treatment": df8[:, 1].tolist(), "time": df8[:, 2].tolist(), "y1_obs": y8,
+    "theta": {"matern12.variance": 1.0, "matern12.lengthscales": 1.0, "categorical.variance": 2.0, "noise": 1e-2},
+    "expected": {"k1_bic": 169.71614261744028, "k": 3, "n": 126},
 }
 # ---- KAT-4: waveome_overview.ipynb cell 4, statement for statement (legacy NumPy RNG; note the sort) ----
 import pandas as pd

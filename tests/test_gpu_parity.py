@@ -284,7 +284,41 @@ def test_fit_reproduces_reference_known_answers(ctx, golden_dir):
         assert th[2] == pytest.approx(e["noise"], rel=5e-6)
         if "lml" in e:
             assert res["lml"][0] == pytest.approx(e["lml"], rel=1e-11)
+        if "expected_full" in c:   # cell 13 of the notebook: the fitted parameters at full precision
+            f = c["expected_full"]
+            full = np.array([f["variance"], f["lengthscales"], f["noise"]])
+            print("KAT-1 device fit vs the notebook's full-precision parameters, relative:", (th[:3] - full) / full)
+            np.testing.assert_allclose(th[:3], full, rtol=1e-9)   # measured 2e-13
+            val, st = prob.lml([0], full[None, :])
+            assert st[0] == 0 and val[0] == pytest.approx(e["lml"], abs=5e-12)
         prob.close()
+
+
+def test_kat8_value_at_fixed_parameters_through_gpu(ctx, golden_dir):
+    """KAT-8 (data_generation.ipynb cell 14): the reference's own log-likelihood of simulated_data.csv's y1_obs under
+    Matern12(1, 1)[time] + Categorical(2)[unit] + 0.01 I, stored as k1_bic = 169.71614261744028 - a value at fixed
+    parameters, through the device Gram / factorisation / LML path (value+gradient call and the value-only call)."""
+    from waveome_amd.engine import Problem
+
+    with open(os.path.join(golden_dir, "kat.json")) as fh:
+        c = json.load(fh)["kat8"]
+    X = np.column_stack([c["unit"], c["treatment"], c["time"]]).astype(float)
+    Y = np.asarray(c["y1_obs"], float).reshape(-1, 1)
+    t, e = c["theta"], c["expected"]
+    kern = K.Sum([K.Matern12(variance=t["matern12.variance"], lengthscales=t["matern12.lengthscales"], active_dims=[2]),
+                  K.Categorical(variance=t["categorical.variance"], active_dims=[0])])
+    ms = ModelSpec(kern, 3, K.GaussianLikelihood(variance=t["noise"]), mean_function=None)
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    theta = ms.theta()
+    val, st = prob.lml([0], theta[None, :])
+    assert st[0] == 0
+    assert e["k"] * np.log(e["n"]) - 2 * val[0] == pytest.approx(e["k1_bic"], rel=1e-12)
+    f, g, st = prob.value_grad([0], ms.unconstrain()[None, :])
+    assert st[0] == 0 and e["k"] * np.log(e["n"]) + 2 * f[0] == pytest.approx(e["k1_bic"], rel=1e-12)
+    # the Gram matrix itself against the oracle's (Matern-1/2 and Categorical entries)
+    Ko = o.gram(ms.to_dict(), theta, X) + t["noise"] * np.eye(len(Y))
+    np.testing.assert_allclose(prob.gram(theta), Ko, rtol=2e-13, atol=2e-13)
+    prob.close()
 
 
 def test_kat5_periodic_known_answer_through_gpu(ctx, golden_dir):

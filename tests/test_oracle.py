@@ -44,6 +44,18 @@ def test_kat1_fit_reproduces_notebook(kat):
     assert r["theta"][2] == pytest.approx(e["noise"], rel=5e-6)
 
 
+def test_kat1_full_precision_parameters(kat):
+    """gpflow_basic_colab.ipynb cell 13 prints the fitted parameters at full precision: SciPy L-BFGS-B on the oracle
+    walks GPflow's 100-iteration path to the same point - the two objectives are the same function to rounding."""
+    c = kat["kat1"]
+    spec, X, Y = _kat_problem(c)
+    full = c["expected_full"]
+    th = np.array([full["variance"], full["lengthscales"], full["noise"]])
+    assert o.lml(spec, th, X, Y) == pytest.approx(c["expected"]["lml"], abs=2e-12)
+    r = o.fit(spec, X, Y, maxiter=100)
+    np.testing.assert_allclose(r["theta"], th, rtol=1e-9)
+
+
 def test_kat2_matern52_fit(kat):
     c = kat["kat2"]
     spec, X, Y = _kat_problem(c)
@@ -72,6 +84,35 @@ def test_kat5_periodic_three_decimals(kat):
     assert r["lml"] == pytest.approx(rec["lml"], rel=1e-9)
     assert (r["nit"], r["nfev"]) == (rec["nit"], rec["nfev"])
     np.testing.assert_allclose(r["theta"][:3], rec["theta"][:3], rtol=1e-5)
+
+
+def _kat8(c):
+    X = np.column_stack([c["unit"], c["treatment"], c["time"]]).astype(float)
+    y = np.asarray(c["y1_obs"], float)
+    spec = o.make_spec(3, [[("m12", [2])], [("cat", [0])]], mean=False)
+    t = c["theta"]
+    theta = np.array([t["matern12.variance"], t["matern12.lengthscales"], t["categorical.variance"], t["noise"]])
+    return spec, theta, X, y
+
+
+def test_kat8_value_at_fixed_parameters_matern12_plus_categorical(kat):
+    """data_generation.ipynb cell 14: the reference evaluates, with SciPy's multivariate normal, the log-likelihood of
+    the y1_obs column of its own simulated_data.csv under Matern12(1, 1)[time] + Categorical(2)[unit] + 0.01 I and stores
+    k1_bic = 3 ln 126 - 2 loglik = 169.71614261744028.  A value at fixed parameters - no optimiser between the stored
+    number and the Gram matrix: Matern-1/2, a Categorical term's VALUE, their Sum and the LML formula to 1e-13."""
+    c = kat["kat8"]
+    spec, theta, X, y = _kat8(c)
+    e = c["expected"]
+    assert len(y) == e["n"] and sum(p["trainable"] for p in spec["params"]) - 1 == e["k"]   # k1's own parameters
+    ll = o.lml(spec, theta, X, y)
+    assert e["k"] * np.log(e["n"]) - 2 * ll == pytest.approx(e["k1_bic"], rel=1e-13)
+    # the same number from the definition the notebook used
+    from scipy.stats import multivariate_normal
+    K = o.gram(spec, theta, X) + theta[3] * np.eye(len(y))
+    assert multivariate_normal(mean=np.zeros(len(y)), cov=K).logpdf(y) == pytest.approx(ll, rel=1e-12)
+    # it discriminates: the Categorical variance alone moves it by whole nats
+    th2 = theta.copy(); th2[2] = 1.0
+    assert abs(o.lml(spec, th2, X, y) - ll) > 1.0
 
 
 def test_kat6_constant_mean_se_bounds_from_the_stored_svgp_fits(kat):
