@@ -502,6 +502,66 @@ def test_batched_fit_matches_scipy_oracle(ctx):
     prob.close()
 
 
+def _free_device_bytes():
+    """hipMemGetInfo through the runtime the library itself is linked against (no torch in this suite's process)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return int(free.value)
+
+
+def test_problem_lifecycles_return_their_device_memory(ctx):
+    """Every path that allocates on the device - single- and multi-structure problems, float64 and float32 storage,
+    fits, prediction at new inputs (its scratch), whitened means, a work queue opened, fed and destroyed mid-way, the
+    optional quad buffer of the trace pass - gives its memory back (a production job creates one problem per structure
+    batch, thousands per search)."""
+    from waveome_amd.engine import Context, FitQueue, Problem, lbfgs_opts
+
+    X, Y = _data(77, 300)
+    ms = ModelSpec(_composite(), 4, K.GaussianLikelihood(), K.ConstantMean())
+    ms2 = ModelSpec(K.SquaredExponential(active_dims=[0]) + K.Lin(active_dims=[1]), 4, K.GaussianLikelihood(),
+                    K.ConstantMean())
+    ctx32 = Context(0, dtype="float32")
+
+    def cycle(i):
+        prob = Problem(ctx, X, Y, ms, max_batch=3)
+        res = prob.fit([0, 1, 2], np.tile(ms.unconstrain(), (3, 1)), lbfgs_opts(maxiter=3))
+        th = ms.constrain(res["u"][0])
+        prob.predict(0, th, Xnew=X[:50] + 0.1)
+        prob.whitened_means(0, th, [1, 2, 3])
+        prob.close()
+        multi = Problem(ctx, X, Y, [ms, ms2], max_batch=4)
+        q = FitQueue(multi, lbfgs_opts(maxiter=50))
+        w = max(ms.n_trainable, ms2.n_trainable)
+        U0 = np.zeros((4, w))
+        U0[:2, :ms.n_trainable] = ms.unconstrain()
+        U0[2:, :ms2.n_trainable] = ms2.unconstrain()
+        q.submit([0, 1, 0, 2], [0, 0, 1, 1], U0, tags=[10, 11, 12, 13])
+        q.advance()
+        q.advance()
+        q.close()            # with fits still in flight
+        multi.close()
+        p32 = Problem(ctx32, X, Y, ms2, max_batch=2)
+        p32.value_grad([0, 1], np.tile(ms2.unconstrain(), (2, 1)))
+        p32.close()
+
+    # The first cycles pay for code objects, streams, pinned staging and the runtime's allocator pools (free memory
+    # drops by some 60 - 140 MiB once, then stays: tests/leak_probe.py ran 200 cycles flat); a leak would show in EVERY
+    # window, so the smallest drop over three windows of 12 cycles is what must vanish.
+    for i in range(6):
+        cycle(i)
+    drops = []
+    for w in range(3):
+        before = _free_device_bytes()
+        for i in range(12):
+            cycle(i)
+        drops.append(before - _free_device_bytes())
+    ctx32.close()
+    assert min(drops) < (4 << 20), f"free device memory fell by {[round(d / 2**20, 1) for d in drops]} MiB per 12 cycles"
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 
