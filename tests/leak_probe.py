@@ -45,7 +45,8 @@ def cyc():
 cyc(); cyc(); f0=free()
 for r in range(8):
     for i in range(25): cyc()
-    print(f"combined: after {25*(r+1)} cycles free fell by {(f0-free())/2**20:.1f} MiB", flush=True)
+    import psutil
+    print(f"combined: after {25*(r+1)} cycles free fell by {(f0-free())/2**20:.1f} MiB; host RSS {psutil.Process().memory_info().rss/2**20:.1f} MiB", flush=True)
 import itertools
 for name,fns in [('fit+predict new',(b,c)),('fit+whitened',(b,d)),('fit+queue',(b,f)),('fit+f32',(b,g)),('queue+f32',(f,g)),('predict+whitened',(c,d))]:
     for fn in fns: fn()
