@@ -562,6 +562,58 @@ def test_problem_lifecycles_return_their_device_memory(ctx):
     assert min(drops) < (4 << 20), f"free device memory fell by {[round(d / 2**20, 1) for d in drops]} MiB per 12 cycles"
 
 
+def test_problems_on_several_host_threads_share_a_context(ctx):
+    """The threading contract of INTEGRATION.md: one wv_ctx shared by host threads, one wv_problem per thread, calls
+    overlapping on the GPU (ctypes releases the GIL).  Four threads fit different structures at the same time; every
+    result equals the one the same call gives alone, bit for bit, and an error raised on one thread (a bad column
+    index) does not leak into the others' last-error state."""
+    import threading
+
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = _data(31, 260)
+    kerns = [K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]) + K.Lin(active_dims=[2]),
+             K.Periodic(K.SquaredExponential(active_dims=[0])), _composite()]
+    specs = [ModelSpec(k, 4, K.GaussianLikelihood(), K.ConstantMean()) for k in kerns]
+    cols = np.array([0, 1, 2], dtype=np.int32)
+
+    def work(ms):
+        prob = Problem(ctx, X, Y, ms, max_batch=3)
+        try:
+            out = []
+            for rep in range(3):
+                res = prob.fit(cols, np.tile(ms.unconstrain(), (3, 1)), lbfgs_opts(maxiter=25))
+                out.append((res["loss"].copy(), res["u"].copy(), res["nfev"].copy()))
+            with pytest.raises(Exception):
+                prob.value_grad([99], ms.unconstrain()[None, :])      # this thread's error only
+            f, g, st = prob.value_grad(cols, np.tile(ms.unconstrain(), (3, 1)))
+            out.append((f, g, st))
+            return out
+        finally:
+            prob.close()
+
+    alone = [work(ms) for ms in specs]
+    got, errs = [None] * len(specs), []
+
+    def runner(i):
+        try:
+            got[i] = work(specs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    for rounds in range(2):
+        threads = [threading.Thread(target=runner, args=(i,)) for i in range(len(specs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        for a, b in zip(alone, got):
+            for ta, tb in zip(a, b):
+                for xa, xb in zip(ta, tb):
+                    np.testing.assert_array_equal(xa, xb)
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 
