@@ -266,6 +266,32 @@ def test_gpsearch_constructor_preprocessing():
     assert abs(g2.Y["petal_length"].std(ddof=1) - 1) < 1e-12
 
 
+def test_reverse_transform_and_the_deprecated_search_entry():
+    """GPSearch.reverse_transform (model_search.py:1677-1715) undoes the constructor's standardisation;
+    run_penalized_search raises like the reference's (:957-959)."""
+    from waveome_amd.model_search import GPSearch
+
+    ir = _iris()
+    X = ir[["sepal_length", "sepal_width", "species"]]
+    Y = ir[["petal_length", "petal_width"]]
+    gps = GPSearch(X=X, Y=Y, categorical_vars=["species"], Y_transform="standardize")
+    back = gps.reverse_transform(gps.X[["sepal_length", "sepal_width"]].to_numpy(), round_digits=6)
+    np.testing.assert_allclose(back, X[["sepal_length", "sepal_width"]].to_numpy(float), atol=1e-6)
+    one = gps.reverse_transform(gps.X["sepal_width"].to_numpy(), feature_name="sepal_width")
+    np.testing.assert_allclose(one, np.round(X["sepal_width"].to_numpy(float), 1), atol=1e-12)
+    yb = gps.reverse_transform(gps.Y["petal_length"].to_numpy(), feature_name="petal_length", input_type="Y", round_digits=6)
+    np.testing.assert_allclose(yb, Y["petal_length"].to_numpy(float), atol=1e-6)
+    scaled = GPSearch(X=X, Y=Y, categorical_vars=["species"], Y_transform="scale")
+    np.testing.assert_allclose(scaled.reverse_transform(scaled.Y.to_numpy(), input_type="Y", round_digits=6),
+                               Y.to_numpy(float), atol=1e-6)
+    with pytest.raises(ValueError):
+        gps.reverse_transform([0.0], input_type="Z")
+    with pytest.raises(AssertionError):
+        GPSearch(X=X, Y=Y, categorical_vars=["species"]).reverse_transform([0.0], input_type="Y")
+    with pytest.raises(NotImplementedError, match="use penalized_optimization instead"):
+        gps.run_penalized_search(random_seed=1)
+
+
 def test_full_kernel_build_structure_and_order():
     from waveome_amd.regularization import full_kernel_build
 

@@ -99,6 +99,27 @@ class GPSearch:
             self.Y = self.Y - self.Y_means
         self.Y = self.Y / self.Y_stds
 
+    def reverse_transform(self, array, feature_name=None, input_type="X", round_digits=1):
+        """Values on the standardised scale back on the caller's scale (model_search.py:1677-1715): x * std + mean with
+        the moments `_standardize_continuous` / `_transform_outputs` kept - for one column (`feature_name`) or, with
+        None, all standardised columns at once (the array's last axis) - rounded to `round_digits` decimals."""
+        if input_type not in ("X", "Y"):
+            raise ValueError("Unknown type requested for transform!")
+        if input_type == "X":
+            assert hasattr(self, "X_stds"), "Standardize_X wasn't called in GPSearch()"
+            scale, shift = self.X_stds, self.X_means
+        else:
+            assert hasattr(self, "Y_stds"), "Y_transform wasn't called in GPSearch()"
+            scale = self.Y_stds
+            shift = getattr(self, "Y_means", None)   # Y_transform="scale" keeps no means
+        pick = (lambda s_: s_.to_numpy()) if feature_name is None else (lambda s_: s_[feature_name])
+        offset = pick(shift) if shift is not None else 0.0
+        return np.round(pick(scale) * np.asarray(array) + offset, decimals=round_digits)
+
+    def run_penalized_search(self, *args, **kwargs):
+        """Deprecated in the reference (model_search.py:933-959): it raises, and so does this."""
+        raise NotImplementedError("run_penalized_search is deprecated, use penalized_optimization instead.")
+
     # ------------------------------------------------------------------------------------------
     def penalized_optimization(self, full_kernel=None, num_jobs=-1, verbose=False, mean_function=None,
                                kernel_options={"second_order_numeric": False,
