@@ -380,6 +380,9 @@ def test_kat6_constant_mean_se_through_the_model_class(ctx, golden_dir):
     assert l2 == pytest.approx(rec["lml_after_restarts"], rel=1e-10)
     elbo2 = (2 * exp["n_parameter_objects"] - exp["after_restarts"]["bic"]) / 2
     assert 0.0 <= l2 - elbo2 <= 0.012
+    m.set_penalization_factor(2.0, use_prior=False)      # the reference's dormant `use_factor` switch (:817-835)
+    assert m.maximum_log_likelihood_objective(use_factor=True) == pytest.approx(l2 - 2.0 * exp["after_restarts"]["kernel.variance"], rel=1e-12)
+    m.set_penalization_factor(0.0, use_prior=False)
     assert abs(m.calc_metric() - exp["after_restarts"]["bic"]) <= 0.02
     assert [round(float(m.kernel.variance.value), 3), round(float(m.likelihood.variance.value), 3)] == \
         exp["after_restarts"]["variance_explained"]

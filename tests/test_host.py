@@ -292,6 +292,23 @@ def test_reverse_transform_and_the_deprecated_search_entry():
         gps.run_penalized_search(random_seed=1)
 
 
+def test_model_methods_refuse_data_that_is_not_their_own():
+    """GPflow's SVGP takes `data` at every call; the mirror holds its data and answers for it only - the training
+    data passed back (what GPSearch does everywhere) is accepted, anything else raises instead of being ignored."""
+    from waveome_amd.model_classes import PSVGP
+
+    rng = np.random.default_rng(0)
+    X, Y = rng.normal(size=(12, 2)), rng.normal(size=(12, 1))
+    m = PSVGP(X, Y)
+    m._own_data_only(None, "x")
+    m._own_data_only((X.copy(), Y[:, 0].copy()), "x")          # (N,) outputs are the same data
+    for other in ((X[:6], Y[:6]), (X + 1e-9, Y), (X, Y * 2)):
+        with pytest.raises(NotImplementedError, match="own training data"):
+            m._own_data_only(other, "calc_metric")
+    with pytest.raises(NotImplementedError, match="own training data"):
+        m.calc_metric(data=(X[:6], Y[:6]))                     # refused before anything touches the GPU
+
+
 def test_full_kernel_build_structure_and_order():
     from waveome_amd.regularization import full_kernel_build
 

@@ -168,6 +168,7 @@ class PSVGP:
         parameters are left as they were and a warning names the outcome."""
         if optimizer not in ("scipy", None):
             raise NotImplementedError("only optimizer='scipy' (L-BFGS-B) is implemented on the GPU path")
+        self._own_data_only(data, "optimize_params")
         self.optimizer = "scipy"
         spec, prob = self._problem()
         opts = lbfgs_opts(maxiter=num_opt_iter)
@@ -191,11 +192,33 @@ class PSVGP:
                           f"{int(res['status'][0])})")
         return None
 
-    def maximum_log_likelihood_objective(self, data=None):
+    def _own_data_only(self, data, what):
+        """The reference's models take `data` at every call (GPflow's SVGP holds none) and GPSearch always passes the
+        training data; this mirror holds its data.  None or the training data itself is fine - anything else is
+        refused instead of silently answering for the training data."""
+        if data is None:
+            return
+        X = np.asarray(data[0], dtype=np.float64)
+        Y = np.asarray(data[1], dtype=np.float64).reshape(len(X), -1)
+        if X.shape != self.data[0].shape or Y.shape != self.data[1].shape or not (
+                np.array_equal(X, self.data[0]) and np.array_equal(Y, self.data[1])):
+            raise NotImplementedError(f"{what}: only the model's own training data is supported on the GPU path "
+                                      "(build a PSVGP on the other data, or use predict_log_density for held-out rows)")
+
+    def maximum_log_likelihood_objective(self, data=None, use_factor=False):
+        """The exact LML (the bound of the reference's SVGP with Z = X at its optimal q).  use_factor: minus
+        penalization_factor x the sum of the variance components - the L1-style penalty the reference keeps behind
+        this switch and never turns on (model_classes.py:817-835)."""
+        self._own_data_only(data, "maximum_log_likelihood_objective")
         spec, prob = self._problem()
         val, st = prob.lml([self._col], spec.theta()[None, :])
         self._release(prob)
-        return float(val[0])
+        out = float(val[0])
+        if use_factor:
+            from .utilities import find_variance_components
+
+            out -= self.penalization_factor * float(np.sum(find_variance_components(self.kernel)))
+        return out
 
     def log_prior_density(self):
         return self._spec().log_prior()
@@ -370,6 +393,7 @@ class PSVGP:
         reference evaluates in calc_feature_importance_components (utilities.py:614-707); with `only`,
         [full, component 0 alone, 1 alone, ...] as individual_kernel_predictions does for calc_rsquare
         (utilities.py:162-172, 770-780)."""
+        self._own_data_only(data, "component_means")
         spec, prob = self._problem(f64=True)
         comps = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
         # additive component k owns a contiguous run of flattened terms (products of sums expand)
