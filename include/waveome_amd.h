@@ -260,7 +260,7 @@ int32_t wv_fit_multi(wv_problem* prob, const int32_t* col_idx, const int32_t* sp
  * Fits are bit-identical to wv_fit_multi's: a batch slot's arithmetic does not depend on its neighbours.
  * One queue per problem at a time, and enforced: while a queue is open the groups' staging buffers and slots are
  * the queue's - a second wv_queue_create and every other device entry point on that problem (wv_fit*, wv_lml,
- * wv_value_grad, wv_gram, wv_predict, wv_whitened_means) answer WV_E_BADARG until wv_queue_destroy; wv_problem_add_spec
+ * wv_value_grad, wv_gram, wv_predict, wv_whitened_means, wv_whitened_state) answer WV_E_BADARG until wv_queue_destroy; wv_problem_add_spec
  * stays allowed.  Not thread-safe (like the problem itself). */
 typedef struct wv_queue wv_queue;
 typedef struct {
@@ -314,6 +314,16 @@ int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const dou
  * jitter = gpflow's default 1e-6.  means_out is n_masks x N. */
 int32_t wv_whitened_means(wv_problem* prob, int32_t col, const double* theta, const uint64_t* term_masks,
                           int32_t n_masks, double jitter, double* means_out);
+
+/* The variational state the reference's model objects carry next to theta (PSVGP.q_mu / PSVGP.q_sqrt, whitened,
+ * inducing points = X: waveome/model_classes.py:99-100, 149-155), at its optimum for the given theta - what the
+ * reference's optimiser converges to and what code downstream of a fit reads off the model:
+ *   q_mu   = L' alpha,                         L = chol(K + jitter I),  alpha = K_y^-1 (y - c)
+ *   q_sqrt = chol((I + L'L / sigma^2)^-1)      (= chol(I - L' K_y^-1 L))
+ * q_mu_out holds N doubles; q_sqrt_out N x N doubles, row-major, lower triangular (strictly upper part zero), or NULL to
+ * skip the two extra factorisations it costs.  Same restrictions as wv_whitened_means; not on the optimisation loop. */
+int32_t wv_whitened_state(wv_problem* prob, int32_t col, const double* theta, double jitter, double* q_mu_out,
+                          double* q_sqrt_out);
 
 /* Timing of the device stages of the most recent wv_value_grad / wv_fit on this
  * problem, measured with HIP events on the stream the kernels ran on.

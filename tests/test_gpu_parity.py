@@ -617,6 +617,48 @@ def test_problems_on_several_host_threads_share_a_context(ctx):
                     np.testing.assert_array_equal(xa, xb)
 
 
+def test_whitened_state_q_mu_and_q_sqrt(ctx):
+    """wv_whitened_state / PSVGP.q_mu, .q_sqrt, .inducing_variable.Z: the SVGP surface of the reference's model objects
+    (model_classes.py:99-100, 149-155), at its optimum for the current parameters - against the definitions evaluated
+    with NumPy on the oracle's Gram matrix, at a padded size and at a multiple of 128."""
+    from waveome_amd.engine import Problem
+    from waveome_amd.model_classes import PSVGP
+
+    for N in (150, 256):
+        X, Y = _data(21, N)
+        kern = K.Sum([K.SquaredExponential(active_dims=[0], lengthscales=0.7), K.Matern32(active_dims=[1]),
+                      K.Categorical(active_dims=[3], variance=0.4)])
+        ms = ModelSpec(kern, 4, K.GaussianLikelihood(variance=0.3), K.ConstantMean(0.2))
+        th = ms.theta()
+        d = ms.to_dict()
+        Kf = o.gram(d, th, X)
+        s2, c = th[ms.noise], th[ms.mean]
+        L = np.linalg.cholesky(Kf + 1e-6 * np.eye(N))
+        Ky = Kf + s2 * np.eye(N)
+        alpha = np.linalg.solve(Ky, Y[:, 1] - c)
+        q_mu_ref = L.T @ alpha
+        S_ref = np.linalg.inv(np.eye(N) + L.T @ L / s2)
+        prob = Problem(ctx, X, Y, ms, max_batch=2)
+        q_mu, q_sqrt = prob.whitened_state(1, th)
+        only_mu, none = prob.whitened_state(1, th, want_sqrt=False)
+        prob.close()
+        assert none is None
+        np.testing.assert_array_equal(only_mu, q_mu)
+        np.testing.assert_allclose(q_mu, q_mu_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(q_mu_ref)))
+        assert np.all(np.triu(q_sqrt, 1) == 0.0) and np.all(np.diag(q_sqrt) > 0)
+        np.testing.assert_allclose(q_sqrt @ q_sqrt.T, S_ref, rtol=0, atol=1e-10 * np.max(np.abs(S_ref)))
+        np.testing.assert_allclose(q_sqrt, np.linalg.cholesky(S_ref), rtol=0, atol=1e-9)
+        # the identity the header states: (I + L'L / s2)^-1 = I - L' K_y^-1 L  (up to the jitter in L)
+        np.testing.assert_allclose(S_ref, np.eye(N) - L.T @ np.linalg.solve(Ky, L), rtol=0, atol=1e-4)
+    m = PSVGP(X, Y[:, 1:2], kernel=kern, context=ctx, penalized_options={"penalization_factor": 0.0})
+    m.likelihood.variance.assign(0.3)
+    m.mean_function.c.assign(0.2)
+    assert m.q_mu.shape == (N, 1) and m.q_sqrt.shape == (1, N, N)
+    np.testing.assert_allclose(m.q_mu[:, 0], q_mu_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(q_mu_ref)))
+    np.testing.assert_array_equal(m.inducing_variable.Z.numpy(), X)
+    assert not m.inducing_variable.Z.trainable
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 

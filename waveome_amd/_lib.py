@@ -106,6 +106,7 @@ SIGNATURES = {
                                  _ip, _ip]),
     "wv_predict": (C.c_int32, [_vp, C.c_int32, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp]),
     "wv_whitened_means": (C.c_int32, [_vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.c_int32, C.c_double, _dp]),
+    "wv_whitened_state": (C.c_int32, [_vp, C.c_int32, _dp, C.c_double, _dp, _dp]),
     "wv_stage_times": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_char_p), _dp,
                                    C.POINTER(C.c_int64), _dp, _dp]),
     "wv_stage_times_reset": (None, [_vp]),

@@ -1263,6 +1263,91 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
   return WV_OK;
 }
 
+// Kbuf(lower) = I + Mbuf(lower) * inv_s2   (the whitened posterior precision I + L'L / sigma^2 from L'L in Mbuf)
+__global__ __launch_bounds__(256) void precision_kernel(double* __restrict__ Kmat, const double* __restrict__ LtL,
+                                                        int64_t Npad, double inv_s2) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > i || j >= Npad) return;
+  Kmat[i * Npad + j] = LtL[i * Npad + j] * inv_s2 + (i == j ? 1.0 : 0.0);
+}
+
+int32_t wv_whitened_state(wv_problem* h, int32_t col, const double* theta, double jitter, double* q_mu_out,
+                          double* q_sqrt_out) {
+  if (!h || !theta || !q_mu_out || col < 0 || col >= h->p.P || !(jitter >= 0)) {
+    set_error("wv_whitened_state: bad argument");
+    return WV_E_BADARG;
+  }
+  Problem& p = h->p;
+  if (p.dmask) {
+    set_error("wv_whitened_state: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
+    return WV_E_UNSUPPORTED;
+  }
+  if (p.specs.size() != 1) {
+    set_error("wv_whitened_state: the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
+  if (p.f32) {
+    set_error("wv_whitened_state: not implemented for float32 problems (create the problem on a float64 context)");
+    return WV_E_UNSUPPORTED;
+  }
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  int rc = enter_device_call(p, "wv_whitened_state");
+  if (rc != WV_OK) return rc;
+  rc = eval_one(p, col, theta);  // alpha
+  if (rc != WV_OK) return rc;
+  Group& g = p.groups[0];
+  if (g.h_status[0] != 0) {
+    set_error("wv_whitened_state: Gram matrix not positive definite at theta");
+    return WV_E_BADARG;
+  }
+  hipStream_t st = g.stream;
+  const int64_t Np = p.Npad, mat = Np * Np;
+  double* K0 = p.Kbuf + (int64_t)g.slot0 * mat;
+  double* M0 = p.Mbuf + (int64_t)g.slot0 * mat;
+  const uint64_t all = p.spec.n_terms() >= 64 ? ~0ull : ((1ull << p.spec.n_terms()) - 1ull);
+  const double s2 = theta[p.spec.noise_param];
+  // L = chol(K + jitter I) in Kbuf; q_mu = L' alpha
+  WV_HIP_TRY(hipMemsetAsync(p.dstatus + g.slot0, 0, sizeof(int32_t), st));
+  launch_gram_masked(p, st, g.slot0, 1, all, jitter);
+  cholesky(p, st, g.slot0, 1);
+  launch_trmv(p, st, p.Kbuf, p.dalpha, p.dr, g.slot0, 1, true);
+  WV_HIP_TRY(hipMemcpyAsync(q_mu_out, p.dr + (int64_t)g.slot0 * Np, sizeof(double) * p.N, hipMemcpyDeviceToHost, st));
+  if (q_sqrt_out) {
+    // L'L (lower) into Mbuf - the product K_y^-1 = M'M runs on, with L in M's place (the blocked factorisation's
+    // diagonal-block inverses in Mbuf are dead once L is complete)
+    GemmArgs a{};
+    a.A = K0; a.B = K0; a.C = M0;
+    a.lda = a.ldb = a.ldc = (int)Np;
+    a.sA = a.sB = a.sC = mat;
+    a.M = (int)Np; a.N = (int)Np; a.kb = 0; a.ke = (int)Np; a.klo_mode = 1; a.koff = 0;
+    a.alpha = 1.0; a.beta = 0.0; a.nbatch = 1;
+    a.tri = 1; a.tri_off = 0;
+    launch_gemm(st, a, false, false, 64);
+    hipLaunchKernelGGL(precision_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, K0, M0, Np,
+                       1.0 / s2);
+    // (I + L'L / sigma^2)^-1 by the factor-and-invert pipeline of the fits, then its Cholesky factor
+    factor_inverse(p, st, g.slot0, 1);
+    lauum(p, st, g.slot0, 1);
+    cholesky(p, st, g.slot0, 1);
+    WV_HIP_TRY(hipMemcpy2DAsync(q_sqrt_out, sizeof(double) * p.N, K0, sizeof(double) * Np, sizeof(double) * p.N, p.N,
+                                hipMemcpyDeviceToHost, st));
+  }
+  WV_HIP_TRY(hipMemcpyAsync(g.h_status, p.dstatus + g.slot0, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  WV_HIP_TRY(hipStreamSynchronize(st));
+  WV_HIP_TRY(hipGetLastError());
+  const int32_t bad = g.h_status[0];
+  if (int rc2 = leave_device_call(WV_OK)) return rc2;
+  if (bad) {
+    set_error("wv_whitened_state: a factorisation met a non-positive pivot");
+    return WV_E_BADARG;
+  }
+  if (q_sqrt_out)
+    for (int64_t i = 0; i < p.N; ++i)
+      for (int64_t j = i + 1; j < p.N; ++j) q_sqrt_out[i * p.N + j] = 0.0;
+  return WV_OK;
+}
+
 int32_t wv_problem_add_spec(wv_problem* h, const wv_kernel_spec* spec, int32_t* index_out) {
   if (!h || !spec || !index_out) {
     set_error("wv_problem_add_spec: null argument");

@@ -324,6 +324,16 @@ class Problem:
                                               float(jitter), _lib.as_dp(out)), "wv_whitened_means")
         return out
 
+    def whitened_state(self, col, theta, jitter=1e-6, want_sqrt=True):
+        """(q_mu [N], q_sqrt [N, N] lower or None): the optimum of the reference's whitened variational state at theta
+        (model_classes.py:99-100, 149-155) - q_mu = chol(K + jitter I)' alpha, q_sqrt = chol((I + L'L / sigma^2)^-1)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        q_mu = np.empty(self.N)
+        q_sqrt = np.empty((self.N, self.N)) if want_sqrt else None
+        _lib.check(self.lib.wv_whitened_state(self.handle, int(col), _lib.as_dp(theta), float(jitter), _lib.as_dp(q_mu),
+                                              _lib.as_dp(q_sqrt) if want_sqrt else None), "wv_whitened_state")
+        return q_mu, q_sqrt
+
     # ---- timing ----
     STAGES = ("gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
               "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce",

@@ -84,6 +84,15 @@ class ProblemPool:
         self._probs = {}
 
 
+class _Inducing:
+    """`model.inducing_variable.Z` of the reference's SVGP: here always the training inputs (exact GP, Z = X)."""
+
+    def __init__(self, X):
+        self.Z = K.Parameter(0.0, transform="identity", trainable=False, name="inducing_variable.Z")
+        self.Z.value = np.asarray(X, dtype=np.float64)        # (a matrix, where kernel parameters are scalars)
+        self.Z.numpy = lambda X=self.Z.value: X
+
+
 class PSVGP:
     def __init__(self, X, Y, mean_function=None, kernel=None, verbose=False, num_latent_gps=1, dtype=None,
                  penalized_options={}, sparse_options={}, variational_options={}, context=None):
@@ -228,6 +237,31 @@ class PSVGP:
 
     def training_loss(self, data=None):
         return -self.log_posterior_density(data)
+
+    # ---- the SVGP surface code downstream of a fit reads off the reference's models --------------------
+    @property
+    def inducing_variable(self):
+        """`.inducing_variable.Z`: the inducing points = the training inputs, not trainable (model_classes.py:99-100, 169)."""
+        return _Inducing(self.data[0])
+
+    def _whitened_state(self, want_sqrt):
+        spec, prob = self._problem(f64=True)
+        try:
+            return prob.whitened_state(self._col, spec.theta(), want_sqrt=want_sqrt)
+        finally:
+            self._release(prob)
+
+    @property
+    def q_mu(self):
+        """[N, 1]: the whitened variational mean at its optimum for the current parameters (what the reference's
+        optimiser drives its 125 k extra variables to): chol(K + 1e-6 I)' K_y^-1 (y - c).  Computed on request."""
+        return self._whitened_state(False)[0][:, None]
+
+    @property
+    def q_sqrt(self):
+        """[1, N, N] lower triangular: the Cholesky factor of the optimal whitened covariance
+        (I + L'L / sigma^2)^-1 (gpflow's FillTriangular layout).  Two extra factorisations, computed on request."""
+        return self._whitened_state(True)[1][None, :, :]
 
     # ---- prediction at the training inputs (the only Xnew this path uses) ----------------
     def _xnew(self, Xnew):
