@@ -291,6 +291,12 @@ class PSVGP:
         self._release(prob)
         return mean[:, None], var[:, None]
 
+    def predict_f_samples(self, Xnew=None, num_samples=None, full_cov=True, full_output_cov=False):
+        """Posterior function draws - what the reference's plotting helpers call (predictions.py); they need the full
+        posterior covariance, which this path does not form (section 8 of DESIGN.md: plotting is out of scope)."""
+        raise NotImplementedError("predict_f_samples needs the full posterior covariance (full_cov=True), which the "
+                                  "GPU path does not compute; predict_f / predict_y give means and variances")
+
     def predict_log_density(self, data):
         """log N(y | mean_f, var_f + sigma^2) per row (gpflow GPModel.predict_log_density, Gaussian likelihood)."""
         X, Y = data
