@@ -617,6 +617,27 @@ def test_problems_on_several_host_threads_share_a_context(ctx):
                     np.testing.assert_array_equal(xa, xb)
 
 
+def test_model_with_noise_on_its_floor_predicts(ctx):
+    """The post-fit steps of a model whose fit ended with the noise variance exactly on its 1e-6 floor (tests/test_host.py
+    has the encoding half): LML, prediction and component means against the oracle at that point."""
+    from waveome_amd.model_classes import PSVGP
+
+    X, Y = _data(5, 90)
+    kern = K.Sum([K.SquaredExponential(active_dims=[0], variance=2.0, lengthscales=0.05),   # short: K_y stays PD
+                  K.Categorical(active_dims=[3], variance=0.5)])
+    m = PSVGP(X, Y[:, :1], kernel=kern, context=ctx, penalized_options={"penalization_factor": 0.0})
+    m.likelihood.variance.assign(1e-6)
+    spec = m._spec()
+    th = spec.theta()
+    assert th[spec.noise] == 1e-6
+    d = spec.to_dict()
+    assert m.maximum_log_likelihood_objective() == pytest.approx(o.lml(d, th, X, Y[:, 0]), rel=1e-9)
+    mean, var = m.predict_y()
+    om, ov = o.predict_train(d, th, X, Y[:, 0])
+    np.testing.assert_allclose(mean[:, 0], om, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var[:, 0], ov, rtol=1e-5, atol=1e-9)
+
+
 def test_whitened_state_q_mu_and_q_sqrt(ctx):
     """wv_whitened_state / PSVGP.q_mu, .q_sqrt, .inducing_variable.Z: the SVGP surface of the reference's model objects
     (model_classes.py:99-100, 149-155), at its optimum for the current parameters - against the definitions evaluated

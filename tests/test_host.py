@@ -214,6 +214,21 @@ def test_spec_transforms_and_prior_match_oracle(lib):
     assert th[6] == 1.0  # frozen categorical variance keeps its init
 
 
+def test_noise_exactly_on_its_floor_is_a_valid_fitted_value(lib):
+    """A fit can end with the likelihood variance exactly on the 1e-6 floor of GPflow's Softplus + Shift transform
+    (softplus(u) drops below the last bit of 1e-6 for u < -50): such a model must still be encodable - found by
+    running the kernel search on the KAT-7 data, where the best model's prediction step was refused."""
+    ms = ModelSpec(K.SquaredExponential(active_dims=[0]), 1, K.GaussianLikelihood(variance=1e-6), K.ConstantMean())
+    u = ms.unconstrain()
+    assert u[2] == -340.0                                       # (variance, lengthscales, noise, mean)
+    assert ms.constrain(u)[ms.noise] == 1e-6
+    tiny = ModelSpec(K.SquaredExponential(active_dims=[0], variance=1e-300), 1, K.GaussianLikelihood(), K.ConstantMean())
+    assert tiny.unconstrain()[0] == -340.0                      # below softplus(-340): the saturation point, not -inf
+    with pytest.raises(Exception, match="noise variance init < 1e-6"):
+        ModelSpec(K.SquaredExponential(active_dims=[0]), 1, K.GaussianLikelihood(variance=9e-7),
+                  K.ConstantMean()).unconstrain()
+
+
 def test_spec_rejects_malformed_input(lib):
     ms = _model()
     cs = ms.to_ctypes()

@@ -118,8 +118,10 @@ std::string Spec::parse(const wv_kernel_spec* s, Spec& out) {
     const auto& p = out.params[i];
     if (p.transform < WV_T_IDENTITY || p.transform > WV_T_SOFTPLUS_SHIFT) return "unknown transform";
     if (p.transform == WV_T_SOFTPLUS && !(p.init > 0)) return "positive parameter with init <= 0";
-    if (p.transform == WV_T_SOFTPLUS_SHIFT && !(p.init > kNoiseFloor))
-      return "noise variance init <= 1e-6";
+    // (a fit can end with the noise exactly ON its floor - softplus(u) below the last bit of 1e-6 for u < -50 - and
+    // the fitted model must stay usable: the floor itself is a valid value, unconstrained at the saturation point)
+    if (p.transform == WV_T_SOFTPLUS_SHIFT && !(p.init >= kNoiseFloor))
+      return "noise variance init < 1e-6";
     if (p.trainable) out.trainable.push_back(i);
   }
   return "";
@@ -147,11 +149,13 @@ void Spec::unconstrain(const double* theta, double* u) const {
     int i = trainable[k];
     switch (params[i].transform) {
       case WV_T_SOFTPLUS:
-        u[k] = inv_softplus(theta[i]);
+        u[k] = std::max(kUFloor, inv_softplus(theta[i]));
         break;
-      case WV_T_SOFTPLUS_SHIFT:
-        u[k] = inv_softplus(theta[i] - kNoiseFloor);
+      case WV_T_SOFTPLUS_SHIFT: {
+        const double x = theta[i] - kNoiseFloor;
+        u[k] = x > 0 ? std::max(kUFloor, inv_softplus(x)) : kUFloor;
         break;
+      }
       default:
         u[k] = theta[i];
     }
