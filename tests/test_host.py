@@ -229,6 +229,18 @@ def test_noise_exactly_on_its_floor_is_a_valid_fitted_value(lib):
                   K.ConstantMean()).unconstrain()
 
 
+def test_structures_beyond_the_device_limits_are_refused_by_name():
+    """A structure the reference would build but one device spec cannot hold (> 64 terms here) raises a
+    NotImplementedError that names the limit - not the C-ABI's bare code - found by tests/api_sweep.py."""
+    big = K.Sum([K.SquaredExponential(active_dims=[d % 4]) * K.Matern12(active_dims=[(d + 1) % 4]) for d in range(70)])
+    ms = ModelSpec(big, 4, K.GaussianLikelihood(), K.ConstantMean())
+    with pytest.raises(NotImplementedError, match=r"70 additive terms \(limit 64\).*140 factors \(limit 128\).*parameters \(limit 256\)"):
+        ms.unconstrain()
+    five = K.Product([K.SquaredExponential(active_dims=[0]) for _ in range(5)])
+    with pytest.raises(NotImplementedError, match="5 factors in one product"):
+        ModelSpec(five, 1, K.GaussianLikelihood(), K.ConstantMean()).to_ctypes()
+
+
 def test_spec_rejects_malformed_input(lib):
     ms = _model()
     cs = ms.to_ctypes()

@@ -85,7 +85,7 @@ double horseshoe_logpdf(double x, double scale, double* dlogp) {
 std::string Spec::parse(const wv_kernel_spec* s, Spec& out) {
   if (!s) return "spec is NULL";
   if (s->n_dims < 1 || s->n_dims > WV_MAX_DIMS) return "n_dims out of range [1, 32]";
-  if (s->n_params < 1 || s->n_params > WV_MAX_PARAMS) return "n_params out of range";
+  if (s->n_params < 1 || s->n_params > WV_MAX_PARAMS) return "n_params out of range (1 .. WV_MAX_PARAMS = 256)";
   if (!s->params || !s->term_start || (s->n_terms > 0 && !s->factors)) return "null table in spec";
   if (s->n_terms < 0) return "n_terms < 0";
   out = Spec();

@@ -149,7 +149,23 @@ class ModelSpec:
         return {"D": self.n_dims, "params": params, "terms": [[dict(f) for f in t] for t in self.terms],
                 "noise": self.noise, "mean": self.mean}
 
+    # what one kernel structure may hold on the device (include/waveome_amd.h)
+    LIMITS = {"columns": 32, "additive terms": 64, "factors": 128, "factors in one product": 4, "parameters": 256}
+
+    def check_limits(self):
+        """Raise NotImplementedError, naming the limit, for a structure the device path cannot hold - before the C-ABI
+        answers with its terser code (the reference would build such a kernel; nothing is ever truncated here)."""
+        have = {"columns": self.n_dims, "additive terms": len(self.terms),
+                "factors": sum(len(t) for t in self.terms),
+                "factors in one product": max((len(t) for t in self.terms), default=0), "parameters": self.n_params}
+        over = [f"{have[k]} {k} (limit {v})" for k, v in self.LIMITS.items() if have[k] > v]
+        if over:
+            raise NotImplementedError("kernel structure beyond what one device structure holds: " + ", ".join(over)
+                                      + " - fit fewer interaction terms at a time (e.g. second_order_numeric=False, "
+                                        "fewer base kernels)")
+
     def to_ctypes(self) -> _lib.KernelSpec:
+        self.check_limits()
         n = self.n_params
         params = (_lib.Param * n)()
         for i, p in enumerate(self.param_objs):
