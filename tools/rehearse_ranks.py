@@ -1,8 +1,10 @@
 """Job-size rehearsal of the sharded GPSearch paths: run the same job in ONE process and under torch.distributed with
 several gloo ranks on the one GPU; the printed checksums must be identical (a fit depends only on its task).
-  python tools/rehearse_ranks.py pen|search                                   (single process)
+  python tools/rehearse_ranks.py pen|pen_iter|pen_restart|sweep|search        (single process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node R --master-addr 127.0.0.1 --master-port P tools/rehearse_ranks.py pen|search
 pen:    GPSearch.penalized_optimization() - N = 900, 4 numeric + 1 categorical inputs, 24 outputs, kerns [SE, Periodic(SE)]
+        (pen_iter: penalization_factor=None, three factor iterations; pen_restart: num_restart=3)
+sweep:  GPSearch.kernel_sweep() on the same data: 3 structures x 24 outputs x 2 restarts
 search: GPSearch.run_search(max_depth=3)  - N = 500, 3 inputs, 32 outputs, default kernel list (tools/run_search_demo.py's job)"""
 import hashlib
 import os
@@ -25,7 +27,7 @@ if "RANK" in os.environ:
     dist.init_process_group(os.environ.get("WV_DIST_BACKEND", "gloo"))
 rank, world = parallel.dist_info()
 t0 = time.perf_counter()
-if mode == "pen":
+if mode in ("pen", "pen_iter", "pen_restart", "sweep"):
     N, P = 900, 24
     rng = np.random.default_rng(9102 + 3)
     X = pd.DataFrame({f"x{d}": rng.uniform(-3, 3, N) for d in range(4)})
@@ -34,12 +36,24 @@ if mode == "pen":
     Y = pd.DataFrame({f"y{p}": sum(a[p, d] * np.sin(w[p, d] * X[f"x{d}"] / X[f"x{d}"].std()) for d in range(4))
                       + 1.0 * (X["cat"] == p % 5) + 0.1 * rng.normal(size=N) for p in range(P)})
     gps = GPSearch(X, Y, categorical_vars=["cat"], Y_transform="standardize")
-    gps.penalized_optimization(kernel_options={"second_order_numeric": False, "categorical_numeric_interactions": True,
-                                               "kerns": [K.SquaredExponential(), K.Periodic(K.SquaredExponential())]},
-                               max_batch=int(os.environ.get("WV_REH_BATCH", "0")) or None)
-    rec = np.asarray(gps.fit_records)
-    blob = rec[:, :5].tobytes() + "|".join(f"{f}:{gps.models[f].kernel_name}" for f in gps.out_names).encode()
-    extra = f"evaluations mean {rec[:, 3].mean():.1f}"
+    if mode == "sweep":     # kernel_sweep: 24 outputs x 3 structures x 2 restarts
+        structures = {"se": K.Sum([K.SquaredExponential(active_dims=[d]) for d in range(4)]),
+                      "per": K.Sum([K.Periodic(K.SquaredExponential(active_dims=[d])) for d in range(2)]
+                                   + [K.Categorical(active_dims=[4])]),
+                      "lin*m32": K.Product([K.Lin(active_dims=[0]), K.Matern32(active_dims=[1])])}
+        tab = gps.kernel_sweep(structures, num_restart=2, random_seed=11, keep_models=False)
+        blob = tab[["loss", "lml", "bic", "nit", "nfev", "status"]].to_numpy(float).tobytes()
+        extra = f"{len(tab)} (output, structure) pairs, evaluations mean {tab['nfev'].mean():.1f}"
+    else:
+        more = {"pen": {}, "pen_iter": {"penalization_factor": None, "num_factor_iter": 3},
+                "pen_restart": {"num_restart": 3, "random_seed": 5}}[mode]
+        gps.penalized_optimization(kernel_options={"second_order_numeric": False, "categorical_numeric_interactions": True,
+                                                   "kerns": [K.SquaredExponential(), K.Periodic(K.SquaredExponential())]},
+                                   max_batch=int(os.environ.get("WV_REH_BATCH", "0")) or None, **more)
+        rec = np.asarray(gps.fit_records)
+        blob = rec[:, :5].tobytes() + "|".join(
+            f"{f}:{gps.models[f].kernel_name}:{gps.models[f].penalization_factor!r}" for f in gps.out_names).encode()
+        extra = f"evaluations mean {rec[:, 3].mean():.1f}"
 else:
     N, P = 500, 32
     rng = np.random.default_rng(0)
