@@ -142,5 +142,72 @@ awkward("outputs on wildly different scales, not standardised",
         pd.DataFrame({"a": x}), pd.DataFrame({"small": 1e-6 * np.sin(x), "big": 1e6 * np.sin(x) + 1e5 * rng.normal(size=40)}))
 awkward("text categories", pd.DataFrame({"a": x, "g": rng.choice(["u", "v", "w"], 40)}),
         pd.DataFrame({"y": np.sin(x)}), categorical_vars=["g"])
+# ---- edges of scale -------------------------------------------------------------------------------------------
+def many_outputs():
+    N, P = 60, 3000
+    xs = rng.normal(size=(N, 2))
+    Y = pd.DataFrame(np.sin(xs[:, :1] * rng.uniform(0.5, 2, P)) + 0.1 * rng.normal(size=(N, P)),
+                     columns=[f"o{p}" for p in range(P)])
+    g = GPSearch(X=pd.DataFrame(xs, columns=["a", "b"]), Y=Y)
+    t0 = time.time()
+    g.penalized_optimization(random_seed=1)
+    return f"{P} outputs x N = {N}: {time.time() - t0:.1f} s, {len(g.models)} models"
+
+
+def many_columns(D):
+    N = 200
+    xs = rng.normal(size=(N, D))
+    g = GPSearch(X=pd.DataFrame(xs, columns=[f"c{d}" for d in range(D)]), Y=pd.DataFrame({"y": xs[:, 0] + np.sin(xs[:, 1])}))
+    try:
+        g.penalized_optimization(random_seed=1)
+    except NotImplementedError as e:
+        return "refused by name: " + str(e)[:90]
+    return g.models["y"].kernel_name
+
+
+def odd_size():
+    N = 4097            # Npad = 4160: one 64-row granule past a multiple of 128
+    xs = rng.uniform(-3, 3, size=(N, 2))
+    g = GPSearch(X=pd.DataFrame(xs, columns=["a", "b"]),
+                 Y=pd.DataFrame({"y": np.sin(xs[:, 0]) + 0.3 * xs[:, 1] + 0.1 * rng.normal(size=N)}))
+    t0 = time.time()
+    g.penalized_optimization(random_seed=1)
+    m = g.models["y"]
+    return f"N = {N}: {time.time() - t0:.1f} s, {m.kernel_name}, noise {float(m.likelihood.variance.value):.4f}"
+
+
+def float32_mode():
+    from waveome_amd.utilities import set_precision
+
+    set_precision("float32")
+    try:
+        N = 700
+        xs = rng.uniform(-3, 3, size=(N, 2))
+        g = GPSearch(X=pd.DataFrame(xs, columns=["a", "b"]),
+                     Y=pd.DataFrame({"y": np.sin(xs[:, 0]) + 0.3 * xs[:, 1] + 0.1 * rng.normal(size=N)}))
+        g.penalized_optimization(random_seed=1)
+        m = g.models["y"]
+        m.get_feature_importances()
+        return f"float32: {m.kernel_name}, noise {float(m.likelihood.variance.value):.4f}, importances {m.feature_importances}"
+    finally:
+        set_precision("float64")
+
+
+def nan_refused():
+    xs = rng.normal(size=(30, 1))
+    y = np.sin(xs[:, 0]); y[3] = np.nan
+    try:
+        GPSearch(X=pd.DataFrame(xs, columns=["a"]), Y=pd.DataFrame({"y": y}))
+    except AssertionError as e:
+        return "refused like the reference: " + str(e)
+    raise AssertionError("NaN in Y accepted")
+
+
+step("scale: 3000 outputs", many_outputs)
+step("scale: 30 input columns", lambda: many_columns(30))
+step("scale: 40 input columns (limit 32)", lambda: many_columns(40))
+step("scale: N = 4097", odd_size)
+step("scale: float32 storage through set_precision", float32_mode)
+step("input: NaN in Y", nan_refused)
 print(f"# {len(failures)} failures" + ("" if not failures else ": " + "; ".join(failures)))
 sys.exit(1 if failures else 0)

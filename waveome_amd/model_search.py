@@ -45,6 +45,7 @@ class GPSearch:
         if standardize_X:
             self._standardize_continuous()
         self._transform_outputs(Y_transform)
+        self.rank_stats = None   # per-rank busy times of the last sharded job (torch.distributed only)
 
     def _block_sort_column(self):
         """Column the device-side copies of the data are sorted by (rows of a unit / category contiguous): candidate
