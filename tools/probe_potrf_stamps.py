@@ -33,4 +33,9 @@ for i in range(1, 13):
     print(f"  {names[i]:32s} {s[i] - s[i - 1]:8d}  {100.0 * (s[i] - s[i - 1]) / tot:5.1f} %")
 inv = [s[16] - s[9], s[17] - s[16], s[18] - s[17], s[19] - s[18], s[10] - s[19]]
 print("  inside the second invert64: 4x4 blocks %d, level 4: %d, 8: %d, 16: %d, 32: %d" % tuple(inv))
+print("  one step of factor64b (Schur block, columns 16-19) seen by thread (15, 15): wait for the 4 x 4 diagonal factor %d, "
+      "wait for the panel %d, own rank-4 update %d  (next step starts %d later)" % (s[21] - s[20], s[22] - s[21], s[23] - s[22], s[24] - s[23]))
+print("    its diagonal thread (4, 4): the 4 x 4 factor and the write of its ten numbers %d" % (s[14] - s[13]))
+print("    a panel thread (15, 4): barrier to first use of the factor (LDS reads issued) %d, the four row solves and their "
+      "LDS writes issued %d, to the far side of the next barrier %d" % (s[26] - s[25], s[27] - s[26], s[28] - s[27]))
 prob.close()

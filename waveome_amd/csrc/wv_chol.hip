@@ -98,8 +98,20 @@ __device__ unsigned long long wv_stamps[32];
   do {                                                                                    \
     if (blockIdx.x == 0 && threadIdx.x == 0) wv_stamps[i] = __builtin_readcyclecounter(); \
   } while (0)
+// thread 255 = block (15, 15): active in every rank-4 update, so its waits show the other phases' lengths
+#define WV_STAMP_LAST(i)                                                                    \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 255) wv_stamps[i] = __builtin_readcyclecounter(); \
+  } while (0)
+// thread 244 = block (15, 4): a panel thread of step 4; thread 68 = block (4, 4): that step's diagonal thread
+#define WV_STAMP_T(i, t)                                                                    \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == (t)) wv_stamps[i] = __builtin_readcyclecounter(); \
+  } while (0)
 #else
 #define WV_STAMP(i)
+#define WV_STAMP_LAST(i)
+#define WV_STAMP_T(i, t)
 #endif
 
 // acc[ia][jc][r] += sum over k in [kbeg, kend) of A(16 ia + 4 blk + e, k) * B(k, 16 jc + 4 ((blk + r0 + r) & 3) + e)
@@ -165,6 +177,8 @@ __device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restr
   bool anybad = false;
   for (int jb = 0; jb < 16; ++jb) {
     R* dbuf = dinfo + DINFO * jb;
+    if (jb == 4) WV_STAMP_LAST(20);
+    if (jb == 4) WV_STAMP_T(13, 68);
     if (ty == jb && tx == jb) {
       // 4 x 4 factor of the diagonal block: the critical path of the whole leaf (four dependent rsqrt per step).  (An
       // LDL' recurrence on v_rcp_f64 reciprocals with the four rsqrt hanging off the chain measured 14 % SLOWER.)
@@ -185,11 +199,15 @@ __device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restr
       }
       dbuf[0] = a[1][0]; dbuf[1] = a[2][0]; dbuf[2] = a[3][0]; dbuf[3] = a[2][1]; dbuf[4] = a[3][1]; dbuf[5] = a[3][2];
       dbuf[6] = inv[0]; dbuf[7] = inv[1]; dbuf[8] = inv[2]; dbuf[9] = inv[3];
+      if (jb == 4) WV_STAMP_T(14, 68);
     }
     __syncthreads();
+    if (jb == 4) WV_STAMP_LAST(21);
+    if (jb == 4) WV_STAMP_T(25, 244);
     if (tx == jb && ty > jb) {  // panel: rows of this thread times inv(L_jj)'
       const R l10 = dbuf[0], l20 = dbuf[1], l30 = dbuf[2], l21 = dbuf[3], l31 = dbuf[4], l32 = dbuf[5];
       const R i0 = dbuf[6], i1 = dbuf[7], i2 = dbuf[8], i3 = dbuf[9];
+      if (jb == 4) WV_STAMP_T(26, 244);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const R x0 = a[r][0] * i0;
@@ -200,8 +218,11 @@ __device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restr
         R* pr = pbuf + (4 * ty + r) * 4;
         pr[0] = x0; pr[1] = x1; pr[2] = x2; pr[3] = x3;
       }
+      if (jb == 4) WV_STAMP_T(27, 244);
     }
     __syncthreads();
+    if (jb == 4) WV_STAMP_LAST(22);
+    if (jb == 4) WV_STAMP_T(28, 244);
     if (tx > jb && ty >= tx) {
       R lr[4][4], lc[4][4];
 #pragma unroll
@@ -218,6 +239,8 @@ __device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restr
 #pragma unroll
           for (int k = 0; k < 4; ++k) a[r][c] -= lr[r][k] * lc[c][k];
     }
+    if (jb == 4) WV_STAMP_LAST(23);
+    if (jb == 5) WV_STAMP_LAST(24);   // (top of the next step)
   }
   return anybad;
 }
