@@ -680,6 +680,39 @@ def test_whitened_state_q_mu_and_q_sqrt(ctx):
     assert not m.inducing_variable.Z.trainable
 
 
+def test_closed_form_rank_two_kernel_n16384(ctx):
+    """A size-independent known answer: Constant + two-level Categorical + noise makes K_y = s I + rank 2, whose exact
+    LML follows from a 3 x 3 capacitance matrix at ANY N (tests/big_n_closed_form.py; run by hand up to N = 98304 = 251 GB,
+    profiles/r03_big_n_closed_form.txt).  Here N = 16384 through the value-only and the value+gradient paths."""
+    import big_n_closed_form as B
+
+    from waveome_amd.engine import Problem
+
+    N = 16384
+    rng = np.random.default_rng(1)
+    lab = rng.integers(0, 2, N).astype(float)
+    X = np.column_stack([rng.normal(size=N), lab])
+    y = 0.7 + 0.5 * (lab == 1) + 0.3 * rng.normal(size=N)
+    v, w, s_ = 0.8, 0.4, 0.09
+    ms = ModelSpec(K.Sum([K.Constant(variance=v), K.Categorical(active_dims=[1], variance=w)]), 2,
+                   K.GaussianLikelihood(variance=s_), mean_function=None)
+    ref = B.closed_form(v, w, s_, lab, y)
+    prob = Problem(ctx, X, y[:, None], ms, max_batch=1)
+    lml, st = prob.lml([0], ms.theta()[None, :])
+    f, g, st2 = prob.value_grad([0], ms.unconstrain()[None, :])
+    prob.close()
+    assert st[0] == 0 and st2[0] == 0
+    assert lml[0] == pytest.approx(ref, rel=1e-10) and -f[0] == pytest.approx(ref, rel=1e-10)
+    u = ms.unconstrain()
+    for k in range(3):
+        up, um = u.copy(), u.copy()
+        up[k] += 1e-5
+        um[k] -= 1e-5
+        tp, tm = ms.constrain(up), ms.constrain(um)
+        num = -(B.closed_form(tp[0], tp[1], tp[2], lab, y) - B.closed_form(tm[0], tm[1], tm[2], lab, y)) / 2e-5
+        assert g[0][k] == pytest.approx(num, rel=2e-5, abs=2e-5)
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 
