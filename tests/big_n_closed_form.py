@@ -15,6 +15,24 @@ from waveome_amd import ModelSpec, kernels as K  # noqa: E402
 from waveome_amd.engine import Context, Problem  # noqa: E402
 
 
+def low_rank_lml(U, d, s, y):
+    """log N(y | 0, U diag(d) U' + s I) from the k x k capacitance matrix (k = columns of U), exact at any N."""
+    N = len(y)
+    D = np.diag(np.asarray(d, float))
+    C = np.eye(U.shape[1]) + D @ (U.T @ U) / s
+    logdet = N * np.log(s) + np.linalg.slogdet(C)[1]
+    Uy = U.T @ y
+    quad = (y @ y - Uy @ np.linalg.solve(C, D @ Uy) / s) / s
+    return -0.5 * quad - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi)
+
+
+def closed_form_lin_poly(v_lin, v_poly, offset, v_const, s, x, y):
+    """Lin(v_lin)[x] + Poly(v_poly, offset, degree 2)[x] + Constant(v_const): (v x x' + o)^2 = v^2 x^2 x'^2 + 2 v o x x' + o^2
+    (waveome/kernels.py:19-32, 56-73), so K = U diag(d) U' with U = [x, x^2, x, 1, 1]."""
+    U = np.stack([x, x * x, x, np.ones_like(x), np.ones_like(x)], axis=1)
+    return low_rank_lml(U, [v_lin, v_poly ** 2, 2 * v_poly * offset, offset ** 2, v_const], s, y)
+
+
 def closed_form(v, w, s, lab, y):
     N = len(y)
     U = np.stack([np.ones(N), (lab == 0).astype(float), (lab == 1).astype(float)], axis=1)   # K = U diag(v, w, w) U'

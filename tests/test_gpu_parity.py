@@ -711,6 +711,45 @@ def test_closed_form_rank_two_kernel_n16384(ctx):
         tp, tm = ms.constrain(up), ms.constrain(um)
         num = -(B.closed_form(tp[0], tp[1], tp[2], lab, y) - B.closed_form(tm[0], tm[1], tm[2], lab, y)) / 2e-5
         assert g[0][k] == pytest.approx(num, rel=2e-5, abs=2e-5)
+    # ... and a full batch at the headline size: 96 outputs in one launch, every LML against its closed form
+    N, P = 2048, 96
+    lab = rng.integers(0, 2, N).astype(float)
+    X = np.column_stack([rng.normal(size=N), lab])
+    Y = 0.7 + 0.5 * (lab == 1)[:, None] * rng.normal(size=P) + 0.3 * rng.normal(size=(N, P))
+    prob = Problem(ctx, X, Y, ms, max_batch=P)
+    cols = np.arange(P, dtype=np.int32)
+    f, g, st = prob.value_grad(cols, np.tile(ms.unconstrain(), (P, 1)))
+    lml, st2 = prob.lml(cols, np.tile(ms.theta(), (P, 1)))
+    prob.close()
+    refs = np.array([B.closed_form(v, w, s_, lab, Y[:, p]) for p in range(P)])
+    assert not st.any() and not st2.any()
+    np.testing.assert_allclose(-f, refs, rtol=1e-11)
+    np.testing.assert_allclose(lml, refs, rtol=1e-11)
+    # Lin + Poly(degree 2) + Constant: also low rank ((v x x' + o)^2 = v^2 x^2 x'^2 + 2 v o x x' + o^2, kernels.py:56-73) -
+    # an exact answer for the two kernels no stored output of the reference pins, at N = 8192
+    N = 8192
+    x = rng.uniform(-1.5, 1.5, N)
+    y = 0.4 * x + 0.3 * x * x - 0.2 + 0.2 * rng.normal(size=N)
+    vl, vp, off, vc, s2 = 0.7, 0.5, 0.8, 0.3, 0.05
+    ms2 = ModelSpec(K.Sum([K.Lin(active_dims=[0], variance=vl), K.Poly(active_dims=[0], variance=vp, offset=off, degree=2),
+                           K.Constant(variance=vc)]), 1, K.GaussianLikelihood(variance=s2), mean_function=None)
+    prob = Problem(ctx, x[:, None], y[:, None], ms2, max_batch=1)
+    lml, st = prob.lml([0], ms2.theta()[None, :])
+    f, g, st2 = prob.value_grad([0], ms2.unconstrain()[None, :])
+    prob.close()
+    ref = B.closed_form_lin_poly(vl, vp, off, vc, s2, x, y)
+    assert st[0] == 0 and st2[0] == 0
+    assert lml[0] == pytest.approx(ref, rel=1e-9) and -f[0] == pytest.approx(ref, rel=1e-9)
+    u = ms2.unconstrain()
+    for k in range(len(u)):
+        up, um = u.copy(), u.copy()
+        up[k] += 1e-5
+        um[k] -= 1e-5
+        vals = []
+        for uu in (up, um):
+            tt = ms2.constrain(uu)        # (Lin variance, Poly variance, Poly offset, Constant variance, noise)
+            vals.append(B.closed_form_lin_poly(tt[0], tt[1], tt[2], tt[3], tt[4], x, y))
+        assert g[0][k] == pytest.approx(-(vals[0] - vals[1]) / 2e-5, rel=5e-5, abs=5e-5)
 
 
 def test_stage_timers_report(ctx):

@@ -248,6 +248,27 @@ def test_lml_matches_scipy_multivariate_normal():
     assert o.lml(spec, th, X, y) == pytest.approx(ref, rel=1e-12)
 
 
+def test_low_rank_kernels_against_their_closed_form():
+    """Lin, Poly, Constant and Categorical Gram matrices have low rank, so the LML of their sums has a closed form
+    through a small capacitance matrix (tests/big_n_closed_form.py): an exact, oracle-independent answer for the two
+    kernels no stored output of the reference pins (Lin: waveome/kernels.py:19-32, Poly: :56-73)."""
+    import big_n_closed_form as B
+
+    rng = np.random.default_rng(0)
+    N = 300
+    x = rng.uniform(-1.5, 1.5, N)
+    y = 0.4 * x + 0.3 * x * x - 0.2 + 0.2 * rng.normal(size=N)
+    spec = o.make_spec(1, [[("lin", [0])], [("poly", [0], {"degree": 2})], [("const", [0])]], mean=False)
+    names = [p["name"] for p in spec["params"]]
+    assert [n.split(".")[-1] for n in names] == ["variance", "variance", "offset", "variance", "variance"]
+    theta = np.array([0.7, 0.5, 0.8, 0.3, 0.05])
+    assert o.lml(spec, theta, x[:, None], y) == pytest.approx(B.closed_form_lin_poly(0.7, 0.5, 0.8, 0.3, 0.05, x, y), rel=1e-11)
+    lab = rng.integers(0, 2, N).astype(float)
+    X = np.column_stack([x, lab])
+    spec2 = o.make_spec(2, [[("const", [0, 1])], [("cat", [1])]], mean=False)
+    assert o.lml(spec2, np.array([0.8, 0.4, 0.09]), X, y) == pytest.approx(B.closed_form(0.8, 0.4, 0.09, lab, y), rel=1e-11)
+
+
 def test_horseshoe_bounds_and_integral():
     # Carvalho-Polson-Scott bounds: (K/2) log(1+4/x^2) < p(x) < K log(1+2/x^2), K = (2 pi^3)^-1/2
     Kc = 1.0 / math.sqrt(2.0 * math.pi**3)
