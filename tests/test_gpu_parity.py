@@ -752,6 +752,61 @@ def test_closed_form_rank_two_kernel_n16384(ctx):
         assert g[0][k] == pytest.approx(-(vals[0] - vals[1]) / 2e-5, rel=5e-5, abs=5e-5)
 
 
+@pytest.mark.parametrize("kind", ["m12", "m32", "m52"])
+def test_matern_family_against_the_state_space_likelihood_n3000(ctx, kind):
+    """Device LML of each Matern kernel against the Kalman-filter likelihood of its stochastic differential equation
+    (tests/statespace_matern.py: O(N), no Gram matrix, nothing shared with the oracle) at N = 3000 - the independent pin
+    of Matern-3/2, which no stored output of the reference covers."""
+    import statespace_matern as S
+
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(11)
+    N = 3000
+    x = rng.uniform(0, 40, N)                 # (unsorted: the device does not care, the filter sorts)
+    y = np.sin(x) + 0.3 * np.cos(2.3 * x) + 0.2 * rng.normal(size=N)
+    cls = {"m12": K.Matern12, "m32": K.Matern32, "m52": K.Matern52}[kind]
+    var, ell, s2, c = 1.7, 0.6, 0.04, 0.3
+    ms = ModelSpec(cls(variance=var, lengthscales=ell, active_dims=[0]), 1, K.GaussianLikelihood(variance=s2),
+                   K.ConstantMean(c))
+    prob = Problem(ctx, x[:, None], y[:, None], ms, max_batch=1)
+    lml, st = prob.lml([0], ms.theta()[None, :])
+    f, g, st2 = prob.value_grad([0], ms.unconstrain()[None, :])
+    prob.close()
+    want = S.kalman_lml(kind, var, ell, s2, x, y, mean=c)
+    assert st[0] == 0 and st2[0] == 0
+    assert lml[0] == pytest.approx(want, rel=1e-8) and -f[0] == pytest.approx(want, rel=1e-8)
+
+
+def test_product_with_a_categorical_factor_against_per_level_state_space_likelihoods(ctx):
+    """Categorical[g] * Matern32[x] + noise on the device against the sum of independent per-level Kalman-filter
+    likelihoods (tests/statespace_matern.py): an exact, oracle-independent value of a PRODUCT term, on rows in random
+    order (dense path) and sorted by label (zero-block skipping) - same number, bit for bit."""
+    import statespace_matern as S
+
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(5)
+    N = 2500
+    x = rng.uniform(0, 60, N)
+    g = rng.integers(0, 7, N).astype(float)
+    y = np.sin(x + g) + 0.2 * rng.normal(size=N)
+    w, v, ell, s2, c = 0.8, 1.6, 0.7, 0.05, 0.1
+    kern = K.Product([K.Categorical(active_dims=[1], variance=w), K.Matern32(active_dims=[0], variance=v, lengthscales=ell)])
+    ms = ModelSpec(kern, 2, K.GaussianLikelihood(variance=s2), K.ConstantMean(c))
+    want = sum(S.kalman_lml("m32", w * v, ell, s2, x[g == lev], y[g == lev], mean=c) for lev in range(7))
+    got = []
+    for order in (np.arange(N), np.argsort(g, kind="stable")):
+        prob = Problem(ctx, np.column_stack([x, g])[order], y[order, None], ms, max_batch=1)
+        lml, st = prob.lml([0], ms.theta()[None, :])
+        f, _, st2 = prob.value_grad([0], ms.unconstrain()[None, :])
+        prob.close()
+        assert st[0] == 0 and st2[0] == 0
+        assert lml[0] == pytest.approx(want, rel=1e-8) and -f[0] == pytest.approx(want, rel=1e-8)
+        got.append((lml[0], f[0]))
+    assert abs(got[0][0] - got[1][0]) <= 1e-9 * abs(want)      # row order changes rounding only
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 
