@@ -807,6 +807,53 @@ def test_product_with_a_categorical_factor_against_per_level_state_space_likelih
     assert abs(got[0][0] - got[1][0]) <= 1e-9 * abs(want)      # row order changes rounding only
 
 
+def test_periodic_factors_of_the_headline_against_their_bessel_series_n2048(ctx):
+    """The Periodic half of the headline structure - one Periodic(SE) factor per column, N = 2048, D = 3 - plus a Lin term,
+    against the closed form of its cosine series (modified-Bessel weights: a low-rank kernel, LML from a 544 x 544
+    capacitance matrix; tests/big_n_closed_form.py).  Value through both device paths, gradient against central
+    differences of the closed form.  The reference pins this kernel to 3 dp on ten points (KAT-5); this is 1e-9 at size."""
+    import big_n_closed_form as B
+
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(8)
+    N, D = 2048, 3
+    X = rng.uniform(-3, 3, size=(N, D))
+    y = np.sin(2 * X[:, 0]) + 0.5 * np.sin(1.3 * X[:, 1]) + 0.2 * X[:, 0] + 0.1 * rng.normal(size=N)
+    pars = [(1.2, 0.8, 1.7), (0.6, 0.4, 2.9), (0.3, 1.5, 0.9)]     # (variance, lengthscale, period) per column
+    vl, s2, c = 0.4, 0.02, 0.1
+    kern = K.Sum([K.Periodic(K.SquaredExponential(variance=v, lengthscales=l, active_dims=[d]), period=p)
+                  for d, (v, l, p) in enumerate(pars)] + [K.Lin(active_dims=[0], variance=vl)])
+    ms = ModelSpec(kern, D, K.GaussianLikelihood(variance=s2), K.ConstantMean(c))
+
+    def closed(theta):
+        cols, ds = [], []
+        for d in range(D):
+            U, w = B.periodic_features(X[:, d], theta[3 * d], theta[3 * d + 1], theta[3 * d + 2])
+            cols.append(U)
+            ds.append(w)
+        U = np.column_stack(cols + [X[:, 0]])
+        return B.low_rank_lml(U, np.concatenate(ds + [[theta[9]]]), theta[10], y - theta[11])
+
+    theta = ms.theta()
+    assert [n.split(".")[-1] for n in ms.param_names] == ["variance", "lengthscales", "period"] * 3 + ["variance", "variance", "c"]
+    want = closed(theta)
+    prob = Problem(ctx, X, y[:, None], ms, max_batch=1)
+    lml, st = prob.lml([0], theta[None, :])
+    f, g, st2 = prob.value_grad([0], ms.unconstrain()[None, :])
+    prob.close()
+    assert st[0] == 0 and st2[0] == 0
+    assert lml[0] == pytest.approx(want, rel=1e-9) and -f[0] == pytest.approx(want, rel=1e-9)
+    u = ms.unconstrain()
+    num = np.zeros_like(u)
+    for k in range(len(u)):
+        up, um = u.copy(), u.copy()
+        up[k] += 1e-5
+        um[k] -= 1e-5
+        num[k] = -(closed(ms.constrain(up)) - closed(ms.constrain(um))) / 2e-5
+    np.testing.assert_allclose(g[0], num, rtol=1e-4, atol=1e-4 * np.max(np.abs(num)))
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 

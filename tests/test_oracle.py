@@ -286,6 +286,28 @@ def test_matern_family_against_the_state_space_likelihood(kind):
         assert o.lml(spec, np.array([var, ell, s2, c]), x[:, None], y) == pytest.approx(want, rel=1e-9)
 
 
+def test_periodic_kernel_against_its_bessel_cosine_series():
+    """The Periodic(SE) kernel - half of the headline structure, pinned by the reference to 3 dp (KAT-5) - against an
+    exact, independent derivation: its cosine series with modified-Bessel weights is a low-rank kernel whose LML has a
+    closed form (tests/big_n_closed_form.py::periodic_features)."""
+    import big_n_closed_form as B
+
+    rng = np.random.default_rng(4)
+    N = 300
+    x = rng.uniform(-3, 3, N)
+    y = np.sin(2.1 * x) + 0.3 * x + 0.2 * rng.normal(size=N)
+    spec = o.make_spec(1, [[("periodic", [0])], [("lin", [0])]], mean=True)
+    assert [p["name"].split(".")[-1] for p in spec["params"]] == ["variance", "lengthscales", "period", "variance", "variance", "c"]
+    for v, ell, per, vl, s2, c in [(1.0, 1.0, 1.0, 1.0, 1.0, 0.0), (1.8, 0.45, 2.7, 0.2, 0.03, 0.3), (0.5, 0.12, 1.3, 0.05, 0.1, -0.1)]:
+        want = B.closed_form_periodic(v, ell, per, vl, s2, x, y, mean=c)
+        assert o.lml(spec, np.array([v, ell, per, vl, s2, c]), x[:, None], y) == pytest.approx(want, rel=1e-10)
+    # the Gram matrix itself from the series
+    U, d = B.periodic_features(x, 1.8, 0.45, 2.7)
+    Kser = (U * d) @ U.T
+    Kor = o.gram(o.make_spec(1, [[("periodic", [0])]], mean=False), np.array([1.8, 0.45, 2.7, 1.0]), x[:, None])
+    np.testing.assert_allclose(Kser, Kor, rtol=0, atol=1e-13)
+
+
 def test_product_with_a_categorical_factor_is_one_independent_gp_per_level():
     """Categorical[g] * Matern32[x] (the unit x numeric / categorical x numeric terms of full_kernel_build,
     waveome/regularization.py:103-149) is block diagonal in the labels: its LML is the sum over the levels of the LML of
