@@ -854,6 +854,42 @@ def test_periodic_factors_of_the_headline_against_their_bessel_series_n2048(ctx)
     np.testing.assert_allclose(g[0], num, rtol=1e-4, atol=1e-4 * np.max(np.abs(num)))
 
 
+def test_headline_objective_against_its_low_rank_closed_form_n2048(ctx):
+    """The metric's own objective on the bench's own inputs (bench.make_inputs, bench.headline_spec; N = 2048) against an
+    answer that never forms a Gram matrix: the headline kernel is numerically low rank (SE: Taylor feature map, Periodic:
+    Bessel cosine series), its LML a capacitance-matrix formula (tests/big_n_closed_form.py::headline_closed_form; the oracle
+    agrees with it to 1e-15 at N = 400).  Eight columns in one launch at the start point, one at a perturbed point with
+    its gradient against central differences of the closed form."""
+    import bench
+    import big_n_closed_form as B
+
+    from waveome_amd.engine import Problem
+
+    X, Y = bench.make_inputs(8)
+    assert X.shape == (2048, 3)
+    ms = bench.headline_spec()
+    prob = Problem(ctx, X, Y.T, ms, max_batch=8)
+    cols = np.arange(8, dtype=np.int32)
+    f, _, st = prob.value_grad(cols, np.tile(ms.unconstrain(), (8, 1)))
+    lml, st2 = prob.lml(cols, np.tile(ms.theta(), (8, 1)))
+    want = np.array([B.headline_closed_form(ms.theta(), X, Y[c]) for c in range(8)])
+    assert not st.any() and not st2.any()
+    np.testing.assert_allclose(-f, want, rtol=1e-10)
+    np.testing.assert_allclose(lml, want, rtol=1e-10)
+    rng = np.random.default_rng(1)
+    u = ms.unconstrain() + 0.3 * rng.normal(size=ms.n_trainable)
+    f1, g1, st3 = prob.value_grad([3], u[None, :])
+    prob.close()
+    assert st3[0] == 0
+    assert -f1[0] == pytest.approx(B.headline_closed_form(ms.constrain(u), X, Y[3]), rel=1e-10)
+    for k in (0, 1, 6, 7, 8, 15, 16):      # an SE variance and lengthscale; a Periodic variance, lengthscale, period; noise; mean
+        up, um = u.copy(), u.copy()
+        up[k] += 1e-5
+        um[k] -= 1e-5
+        num = -(B.headline_closed_form(ms.constrain(up), X, Y[3]) - B.headline_closed_form(ms.constrain(um), X, Y[3])) / 2e-5
+        assert g1[0][k] == pytest.approx(num, rel=2e-4, abs=2e-4), k
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 

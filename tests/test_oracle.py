@@ -308,6 +308,32 @@ def test_periodic_kernel_against_its_bessel_cosine_series():
     np.testing.assert_allclose(Kser, Kor, rtol=0, atol=1e-13)
 
 
+def test_headline_structure_against_its_low_rank_closed_form():
+    """The BASELINE headline structure sum_d (SE[d] + Periodic(SE)[d]) + Constant mean is, to rounding, a kernel of rank
+    a few hundred on bounded inputs (SE: Taylor feature map; Periodic: Bessel cosine series), so its exact LML follows
+    from one capacitance matrix at ANY N - an answer for the metric's own objective that never forms a Gram matrix
+    (tests/big_n_closed_form.py::headline_closed_form).  The SE Gram matrix itself against its series, too."""
+    import bench
+    import big_n_closed_form as B
+
+    saved = bench.N_HEAD
+    bench.N_HEAD = 400
+    try:
+        X, Y = bench.make_inputs(2)
+    finally:
+        bench.N_HEAD = saved
+    ms = bench.headline_spec()
+    d = ms.to_dict()
+    rng = np.random.default_rng(0)
+    for col, theta in ((0, ms.theta()), (1, ms.constrain(ms.unconstrain() + 0.4 * rng.normal(size=ms.n_trainable)))):
+        assert o.lml(d, theta, X, Y[col]) == pytest.approx(B.headline_closed_form(theta, X, Y[col]), rel=1e-12)
+    x = X[:, 0]
+    for ell in (0.3, 1.0, 2.5):
+        U, w = B.se_features(x, 1.3, ell)
+        Kor = o.gram(o.make_spec(1, [[("se", [0])]], mean=False), np.array([1.3, ell, 1.0]), x[:, None])
+        np.testing.assert_allclose((U * w) @ U.T, Kor, rtol=0, atol=2e-13)
+
+
 def test_product_with_a_categorical_factor_is_one_independent_gp_per_level():
     """Categorical[g] * Matern32[x] (the unit x numeric / categorical x numeric terms of full_kernel_build,
     waveome/regularization.py:103-149) is block diagonal in the labels: its LML is the sum over the levels of the LML of
