@@ -125,8 +125,26 @@ def cpu_baseline_measure(X, Y, seconds_budget=24.0):
                   "evaluations_per_worker": k_b, "seconds": round(busy, 2), "pool_wall_seconds": round(wall, 2)}
     except Exception as exc:  # a refused child process must not cost the bench line
         mode_b = {"error": repr(exc)}
+    # the parity half of the metric ("log-marg-lik rel-err"): column 0 at the start point by the oracle port and by a
+    # closed form that forms no Gram matrix (oracle/closed_forms.py); the device value is compared after the run
+    from oracle import gp_oracle, closed_forms
+
+    theta0 = np.asarray(headline_spec().theta(), dtype=np.float64)
+    check = {"oracle_port": float(gp_oracle.lml(spec, theta0, X, Y[0])),
+             "closed_form": float(closed_forms.headline_closed_form(theta0, X, Y[0]))}
     return {"ncpu": ncpu, "blas_threads": blas_threads, "workers": workers, "all_threads_one_fit": mode_a,
-            "one_fit_per_core": mode_b}
+            "one_fit_per_core": mode_b, "lml_check": check}
+
+
+def lml_rel_err(raw, device_lml):
+    """{"value": worst relative error of the device LML of column 0 at the start point against the two CPU answers, ...}"""
+    c = raw["lml_check"]
+    errs = {k: abs(device_lml - v) / abs(v) for k, v in c.items()}
+    return {"value": max(errs.values()), "device_lml": device_lml, "vs_oracle_port": errs["oracle_port"],
+            "vs_gram_free_closed_form": errs["closed_form"], "tolerance_north_star": 1e-6,
+            "what": "log marginal likelihood of bench column 0 at the GPflow default parameters: device (wv_lml) against "
+                    "oracle/gp_oracle.py (dense LAPACK) and against oracle/closed_forms.py (the headline kernel's exact "
+                    "low-rank series: no Gram matrix); relative"}
 
 
 def cpu_baseline_finish(raw, evals_per_fit):
@@ -481,6 +499,9 @@ def main():
                          if v["bytes"] > 0 and v["ms"] > 0}}
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_finish(cpu_raw, float(table[:, 3].mean()))
+            dev_lml, dev_st = prob.lml([0], spec.theta()[None, :])      # after the timed region
+            if int(dev_st[0]) == 0:
+                out["cpu_baseline"]["lml_rel_err"] = lml_rel_err(cpu_raw, float(dev_lml[0]))
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     prob.close()

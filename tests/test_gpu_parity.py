@@ -857,7 +857,7 @@ def test_periodic_factors_of_the_headline_against_their_bessel_series_n2048(ctx)
 def test_headline_objective_against_its_low_rank_closed_form_n2048(ctx):
     """The metric's own objective on the bench's own inputs (bench.make_inputs, bench.headline_spec; N = 2048) against an
     answer that never forms a Gram matrix: the headline kernel is numerically low rank (SE: Taylor feature map, Periodic:
-    Bessel cosine series), its LML a capacitance-matrix formula (tests/big_n_closed_form.py::headline_closed_form; the oracle
+    Bessel cosine series), its LML a capacitance-matrix formula (oracle/closed_forms.py::headline_closed_form; the oracle
     agrees with it to 1e-15 at N = 400).  Eight columns in one launch at the start point, one at a perturbed point with
     its gradient against central differences of the closed form."""
     import bench

@@ -289,7 +289,7 @@ def test_matern_family_against_the_state_space_likelihood(kind):
 def test_periodic_kernel_against_its_bessel_cosine_series():
     """The Periodic(SE) kernel - half of the headline structure, pinned by the reference to 3 dp (KAT-5) - against an
     exact, independent derivation: its cosine series with modified-Bessel weights is a low-rank kernel whose LML has a
-    closed form (tests/big_n_closed_form.py::periodic_features)."""
+    closed form (oracle/closed_forms.py::periodic_features)."""
     import big_n_closed_form as B
 
     rng = np.random.default_rng(4)
@@ -312,7 +312,7 @@ def test_headline_structure_against_its_low_rank_closed_form():
     """The BASELINE headline structure sum_d (SE[d] + Periodic(SE)[d]) + Constant mean is, to rounding, a kernel of rank
     a few hundred on bounded inputs (SE: Taylor feature map; Periodic: Bessel cosine series), so its exact LML follows
     from one capacitance matrix at ANY N - an answer for the metric's own objective that never forms a Gram matrix
-    (tests/big_n_closed_form.py::headline_closed_form).  The SE Gram matrix itself against its series, too."""
+    (oracle/closed_forms.py::headline_closed_form).  The SE Gram matrix itself against its series, too."""
     import bench
     import big_n_closed_form as B
 
