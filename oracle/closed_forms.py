@@ -5,6 +5,8 @@ waveome_amd/.  Independent of gp_oracle.py: nothing here forms a Gram matrix or 
   low_rank_lml            log N(y | 0, U diag(d) U' + s I) from the k x k capacitance matrix (determinant lemma, Woodbury)
   se_features             SquaredExponential as its Taylor feature map (exact to rounding on bounded inputs)
   periodic_features       gpflow Periodic(SquaredExponential) as its cosine series with modified-Bessel weights
+  low_rank_predict        posterior mean / variance of f at new rows for the same model (Bayesian linear regression in the features)
+  headline_features       the (U, d) pair of the headline structure, shared feature count for training and new inputs
   headline_closed_form    BASELINE's headline structure sum_d (SE[d] + Periodic(SE)[d]) + Constant mean: rank ~650
   closed_form_lin_poly    Lin + Poly(degree 2) + Constant (waveome/kernels.py:19-32, 56-73)
   closed_form_periodic    Periodic(SE) + Lin
@@ -46,6 +48,48 @@ def periodic_features(x, variance, lengthscale, period, J=90):
         cols += [np.cos(j * phi), np.sin(j * phi)]
         d += [wj, wj]
     return np.stack(cols, axis=1), np.array(d)
+
+
+def low_rank_predict(U, d, s, y, Ustar):
+    """Posterior mean and variance of f at rows Ustar for y ~ N(0, U diag(d) U' + s I): the Bayesian linear model in the
+    feature weights w ~ N(0, diag(d)) - posterior covariance (diag(1/d) + U'U / s)^-1 = D - D G (I + D G)^-1 D ... written
+    with the capacitance matrix C = I + D U'U / s so that zero weights d are fine: S = C^-1 D, m = S U'y / s."""
+    D = np.diag(np.asarray(d, float))
+    C = np.eye(U.shape[1]) + D @ (U.T @ U) / s
+    S = np.linalg.solve(C, D)                       # posterior covariance of the weights
+    m = S @ (U.T @ y) / s
+    return Ustar @ m, np.einsum("ij,jk,ik->i", Ustar, S, Ustar)
+
+
+def headline_features(theta, X, like=None):
+    """(U, d) of the headline structure at inputs X; `like`: the inputs whose range fixes how many SE features are kept
+    (pass the training inputs when X are new points, so that both use the same feature set)."""
+    D_ = X.shape[1]
+    ref = X if like is None else np.vstack([like, X])
+    cols, ds = [], []
+    for dd in range(D_):
+        n = se_features(ref[:, dd], theta[2 * dd], theta[2 * dd + 1])[0].shape[1]
+        U, w = _se_features_n(X[:, dd], theta[2 * dd], theta[2 * dd + 1], n)
+        cols.append(U)
+        ds.append(w)
+    for dd in range(D_):
+        o = 2 * D_ + 3 * dd
+        U, w = periodic_features(X[:, dd], theta[o], theta[o + 1], theta[o + 2])
+        cols.append(U)
+        ds.append(w)
+    return np.column_stack(cols), np.concatenate(ds)
+
+
+def _se_features_n(x, variance, lengthscale, n):
+    from scipy.special import gammaln
+
+    z = np.asarray(x, float) / lengthscale
+    ns = np.arange(n)
+    with np.errstate(divide="ignore"):
+        logphi = ns[None, :] * np.log(np.abs(z))[:, None] - 0.5 * gammaln(ns + 1)[None, :] - 0.5 * (z * z)[:, None]
+    U = np.where((z[:, None] < 0) & (ns[None, :] % 2 == 1), -1.0, 1.0) * np.exp(logphi)
+    U[:, 0] = np.exp(-0.5 * z * z)
+    return U, np.full(n, float(variance))
 
 
 def se_features(x, variance, lengthscale):

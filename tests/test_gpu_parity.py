@@ -890,6 +890,37 @@ def test_headline_objective_against_its_low_rank_closed_form_n2048(ctx):
         assert g1[0][k] == pytest.approx(num, rel=2e-4, abs=2e-4), k
 
 
+def test_headline_predictions_against_the_low_rank_posterior_n2048(ctx):
+    """wv_predict on the headline structure at the bench size - posterior mean and variance at the training inputs and at
+    new inputs - against Bayesian linear regression in the kernel's exact features (oracle/closed_forms.py::low_rank_predict:
+    a 650 x 650 solve, no Gram matrix).  The oracle covers prediction at N ~ 100; this is the size the metric runs at."""
+    import bench
+    from oracle import closed_forms as CF
+
+    from waveome_amd.engine import Problem
+
+    X, Y = bench.make_inputs(2)
+    ms = bench.headline_spec()
+    rng = np.random.default_rng(2)
+    theta = ms.constrain(ms.unconstrain() + 0.3 * rng.normal(size=ms.n_trainable))
+    theta[15] = 0.05                                           # a realistic noise level
+    Xnew = rng.uniform(-1.7, 1.7, size=(60, 3))
+    prob = Problem(ctx, X, Y.T, ms, max_batch=2)
+    m_tr, v_tr = prob.predict(1, theta, include_noise=False)
+    m_new, v_new = prob.predict(1, theta, include_noise=True, Xnew=Xnew)
+    prob.close()
+    U, d = CF.headline_features(theta, X)
+    Un, _ = CF.headline_features(theta, Xnew, like=X)
+    assert U.shape[1] == Un.shape[1]
+    r = Y[1] - theta[16]
+    want_m, want_v = CF.low_rank_predict(U, d, theta[15], r, U)
+    np.testing.assert_allclose(m_tr, want_m + theta[16], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v_tr, want_v, rtol=0, atol=1e-8)
+    want_m, want_v = CF.low_rank_predict(U, d, theta[15], r, Un)
+    np.testing.assert_allclose(m_new, want_m + theta[16], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v_new, want_v + theta[15], rtol=0, atol=1e-8)
+
+
 def test_stage_timers_report(ctx):
     from waveome_amd.engine import Problem
 
