@@ -8,6 +8,7 @@ waveome_amd/.  Independent of gp_oracle.py: nothing here forms a Gram matrix or 
   low_rank_predict        posterior mean / variance of f at new rows for the same model (Bayesian linear regression in the features)
   headline_features       the (U, d) pair of the headline structure, shared feature count for training and new inputs
   headline_closed_form    BASELINE's headline structure sum_d (SE[d] + Periodic(SE)[d]) + Constant mean: rank ~650
+  spec_features / spec_closed_form   ANY structure built from SE, Periodic, Lin, Poly, Constant, Categorical factors (sums of products)
   closed_form_lin_poly    Lin + Poly(degree 2) + Constant (waveome/kernels.py:19-32, 56-73)
   closed_form_periodic    Periodic(SE) + Lin
   closed_form             Constant + two-level Categorical (rank two: usable at N = 98304)
@@ -33,7 +34,7 @@ def closed_form_lin_poly(v_lin, v_poly, offset, v_const, s, x, y):
     return low_rank_lml(U, [v_lin, v_poly ** 2, 2 * v_poly * offset, offset ** 2, v_const], s, y)
 
 
-def periodic_features(x, variance, lengthscale, period, J=90):
+def periodic_features(x, variance, lengthscale, period, J=None):
     """The Periodic(SquaredExponential) kernel v exp(-sin^2(pi tau / p) / (2 l^2)) as a cosine series: with a = 1 / (4 l^2),
     exp(-a) exp(a cos phi) = e^-a I_0(a) + 2 sum_j e^-a I_j(a) cos(j phi), phi = 2 pi tau / p - the modified Bessel functions
     decay factorially in j, so 2 J + 1 features (1, cos j phi_x, sin j phi_x) reproduce the kernel to rounding: a low-rank
@@ -41,6 +42,10 @@ def periodic_features(x, variance, lengthscale, period, J=90):
     from scipy.special import ive
 
     a = 1.0 / (4.0 * lengthscale ** 2)
+    if J is None:   # as many harmonics as carry weight: e^-a I_j(a) falls factorially once j > a
+        J = 1
+        while ive(J, a) > 1e-22 * ive(0, a) and J < 4000:
+            J += 1
     phi = 2.0 * np.pi * np.asarray(x, float) / period
     cols, d = [np.ones_like(phi)], [variance * ive(0, a)]
     for j in range(1, J + 1):
@@ -146,3 +151,72 @@ def closed_form(v, w, s, lab, y):
     Uy = U.T @ y
     quad = (y @ y - Uy @ np.linalg.solve(C, D @ Uy) / s) / s
     return -0.5 * quad - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# any structure whose factors are low rank: sums of products of SE / Periodic (on bounded inputs), Lin, Poly, Constant,
+# Categorical - e.g. everything waveome's full_kernel_build makes from kerns = [SE, Periodic(SE), Lin]
+# ---------------------------------------------------------------------------------------------------------------------
+def _factor_features(f, theta, X, ref):
+    """(U, w) with k_f(x, x') = sum_j w_j U_j(x) U_j(x'); `ref`: the inputs that fix the SE feature counts."""
+    t, dims, p = f["type"], list(f["dims"]), f["p"]
+    n = X.shape[0]
+    if t == "const":
+        return np.ones((n, 1)), np.array([theta[p[0]]])
+    if t == "lin":
+        return X[:, dims], np.full(len(dims), theta[p[0]])
+    if t == "cat":
+        lab = np.rint(X[:, dims[0]])
+        levels = np.unique(np.rint(ref[:, dims[0]]))
+        return (lab[:, None] == levels[None, :]).astype(float), np.full(len(levels), theta[p[0]])
+    if t == "se":
+        U, w = np.ones((n, 1)), np.array([theta[p[0]]])
+        for d in dims:   # an SE over several columns is the product of one-column SEs (the variance counted once)
+            nd = se_features(ref[:, d], 1.0, theta[p[1]])[0].shape[1]
+            Ud, _ = _se_features_n(X[:, d], 1.0, theta[p[1]], nd)
+            U = (U[:, :, None] * Ud[:, None, :]).reshape(n, -1)
+            w = np.repeat(w, nd)
+        return U, w
+    if t == "periodic":
+        if len(dims) != 1:
+            raise NotImplementedError("Periodic on several columns")
+        return periodic_features(X[:, dims[0]], theta[p[0]], theta[p[1]], theta[p[2]])
+    if t == "poly":
+        if len(dims) != 1:
+            raise NotImplementedError("Poly on several columns")
+        from math import comb
+
+        x, v, off, deg = X[:, dims[0]], theta[p[0]], theta[p[1]], int(f["degree"])
+        U = np.stack([x ** k for k in range(deg + 1)], axis=1)       # (v x x' + o)^deg = sum_k C(deg, k) v^k o^(deg-k) (x x')^k
+        return U, np.array([comb(deg, k) * v ** k * off ** (deg - k) for k in range(deg + 1)])
+    if t == "empty":
+        return np.zeros((n, 1)), np.zeros(1)
+    raise NotImplementedError(f"no finite feature map for kernel type {t!r} (the Matern family: see tests/statespace_matern.py)")
+
+
+def spec_features(spec, theta, X, like=None, max_rank=8000):
+    """(U, d) of a whole structure in oracle/gp_oracle.py's spec format (waveome_amd.ModelSpec.to_dict()): a product term's
+    features are the row-wise Kronecker product of its factors' features, its weights their Kronecker product."""
+    X = np.asarray(X, float)
+    ref = X if like is None else np.vstack([np.asarray(like, float), X])
+    cols, ds, total = [], [], 0
+    for term in spec["terms"]:
+        parts = [_factor_features(f, theta, X, ref) for f in term]
+        rank = int(np.prod([u.shape[1] for u, _ in parts]))
+        total += rank
+        if total > max_rank:   # (products of wide feature maps: the capacitance matrix would not fit - not a closed form any more)
+            raise ValueError(f"structure of rank > {max_rank}: no practical closed form")
+        U, w = np.ones((X.shape[0], 1)), np.ones(1)
+        for Uf, wf in parts:
+            U = (U[:, :, None] * Uf[:, None, :]).reshape(X.shape[0], -1)
+            w = (w[:, None] * wf[None, :]).reshape(-1)
+        cols.append(U)
+        ds.append(w)
+    return np.column_stack(cols), np.concatenate(ds)
+
+
+def spec_closed_form(spec, theta, X, y, max_rank=8000):
+    """Exact LML of a low-rank structure (no Gram matrix): see spec_features."""
+    U, d = spec_features(spec, theta, X, max_rank=max_rank)
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    return low_rank_lml(U, d, theta[spec["noise"]], np.asarray(y, float) - c)

@@ -1133,6 +1133,10 @@ def test_config_c4_ihmp_shape_six_structures(ctx):
         for p in range(3):
             ref = o.lml(d, th, X, Y[:, p])
             assert st[p] == 0 and abs(lml[p] - ref) <= 1e-10 * abs(ref), (name, p, lml[p], ref)
+            if name in ("se", "per", "lin"):   # structures of finite rank: also against the Gram-free closed form
+                from oracle import closed_forms as CF
+
+                assert lml[p] == pytest.approx(CF.spec_closed_form(d, th, X, Y[:, p]), rel=1e-10), (name, p)
         prob.close()
 
 
@@ -1166,6 +1170,24 @@ def test_config_c3_composite_n4096(ctx):
     lp, _, _ = prob.value_grad([0], (u + h * dvec)[None, :])
     lm, _, _ = prob.value_grad([0], (u - h * dvec)[None, :])
     assert float(g0[0] @ dvec) == pytest.approx((lp[0] - lm[0]) / (2 * h), rel=2e-6, abs=1e-6)
+    # ... and the objective itself against an answer that forms no Gram matrix: all 17 terms are low rank (SE: Taylor
+    # feature map, Periodic: Bessel series, Categorical: one-hot, products: row-wise Kronecker products), so the exact LML
+    # is one capacitance-matrix formula (oracle/closed_forms.py::spec_closed_form) - at the start point and, with the
+    # penalised loss and the DIRECTIONAL derivative (central differences of the closed form), at a perturbed point
+    from oracle import closed_forms as CF
+
+    d = ms.to_dict()
+    assert lml[0] == pytest.approx(CF.spec_closed_form(d, th, X, y), rel=1e-10)
+    u1 = u + 0.2 * rng.normal(size=len(u))
+
+    def closed_loss(uu):
+        t = ms.constrain(uu)
+        return -(CF.spec_closed_form(d, t, X, y) + o.log_prior(d, t))
+
+    l1, g1, st1 = prob.value_grad([0], u1[None, :])
+    assert st1[0] == 0 and l1[0] == pytest.approx(closed_loss(u1), rel=1e-10)
+    assert float(g1[0] @ dvec) == pytest.approx((closed_loss(u1 + h * dvec) - closed_loss(u1 - h * dvec)) / (2 * h),
+                                               rel=1e-5, abs=1e-5)
     prob.close()
 
 

@@ -334,6 +334,46 @@ def test_headline_structure_against_its_low_rank_closed_form():
         np.testing.assert_allclose((U * w) @ U.T, Kor, rtol=0, atol=2e-13)
 
 
+def test_random_low_rank_structures_against_their_closed_form():
+    """Seeded random sums of products over the kernels that have a finite feature map - SE (one and two columns),
+    Periodic, Lin, Poly (degree 2, 3), Categorical, Constant - : the oracle's LML against the capacitance-matrix closed
+    form (oracle/closed_forms.py::spec_closed_form; features of a product = row-wise Kronecker product).  Two
+    derivations, no shared code: what makes either wrong makes them disagree."""
+    from oracle import closed_forms as CF
+    from waveome_amd import ModelSpec, kernels as K
+
+    kinds = [lambda r: K.SquaredExponential(active_dims=[int(r.integers(0, 3))], variance=r.uniform(.4, 2), lengthscales=r.uniform(.5, 2)),
+             lambda r: K.Periodic(K.SquaredExponential(active_dims=[int(r.integers(0, 3))], variance=r.uniform(.4, 2),
+                                                       lengthscales=r.uniform(.4, 2)), period=r.uniform(.5, 3)),
+             lambda r: K.Lin(active_dims=[int(r.integers(0, 3))], variance=r.uniform(.2, 1)),
+             lambda r: K.Poly(active_dims=[int(r.integers(0, 3))], variance=r.uniform(.2, 1), offset=r.uniform(.3, 1.5),
+                              degree=int(r.integers(2, 4))),
+             lambda r: K.Categorical(active_dims=[3], variance=r.uniform(.2, 1)),
+             lambda r: K.Constant(variance=r.uniform(.2, 1)),
+             lambda r: K.SquaredExponential(active_dims=[0, 1], variance=r.uniform(.4, 2), lengthscales=r.uniform(.7, 2))]
+    done = 0
+    for seed in range(30):
+        r = np.random.default_rng(seed)
+        terms = []
+        for _ in range(int(r.integers(1, 5))):
+            fs = [kinds[int(r.integers(len(kinds)))](r) for _ in range(int(r.integers(1, 3)))]
+            terms.append(fs[0] if len(fs) == 1 else K.Product(fs))
+        ms = ModelSpec(terms[0] if len(terms) == 1 else K.Sum(terms), 4, K.GaussianLikelihood(variance=r.uniform(.02, .5)),
+                       K.ConstantMean(0.3 * r.normal()))
+        rr = np.random.default_rng(1000 + seed)
+        X = rr.normal(size=(150, 4))
+        X[:, 3] = rr.integers(0, 3, 150)
+        y = np.sin(X[:, 0]) + 0.3 * X[:, 1] + 0.2 * rr.normal(size=150)
+        d, th = ms.to_dict(), ms.theta()
+        try:
+            want = CF.spec_closed_form(d, th, X, y, max_rank=2500)
+        except ValueError:      # products of wide feature maps: rank beyond what a closed form is practical for
+            continue
+        assert o.lml(d, th, X, y) == pytest.approx(want, rel=1e-10), seed
+        done += 1
+    assert done >= 15
+
+
 def test_product_with_a_categorical_factor_is_one_independent_gp_per_level():
     """Categorical[g] * Matern32[x] (the unit x numeric / categorical x numeric terms of full_kernel_build,
     waveome/regularization.py:103-149) is block diagonal in the labels: its LML is the sum over the levels of the LML of
