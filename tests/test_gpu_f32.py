@@ -193,6 +193,36 @@ def test_config_c5_float32_n16384(ctx32, ctx64):
     assert np.max(np.abs(g32 - g64)) <= 2e-2 * np.max(np.abs(g64))
 
 
+def test_f32_matern32_against_the_state_space_likelihood_n8192(ctx32, ctx64):
+    """C5's kernel (Matern-3/2) on the float32 path against an answer that is neither the float64 device path nor the
+    oracle: the Kalman-filter likelihood of its stochastic differential equation (tests/statespace_matern.py), N = 8192
+    on one column.  The float64 path lands on it to 1e-8; float32 storage costs the usual ~1e-5 of the log-determinant."""
+    import statespace_matern as S
+
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(6)
+    N = 8192
+    x = rng.uniform(0, 80, N)
+    y = np.sin(x) + 0.4 * np.cos(0.37 * x) + 0.3 * rng.normal(size=N)
+    var, ell, s2, c = 1.4, 0.8, 0.3, 0.1
+    ms = ModelSpec(K.Matern32(variance=var, lengthscales=ell, active_dims=[0]), 1, K.GaussianLikelihood(variance=s2),
+                   K.ConstantMean(c))
+    want = S.kalman_lml("m32", var, ell, s2, x, y, mean=c)
+    got = {}
+    for name, cx in (("f64", ctx64), ("f32", ctx32)):
+        prob = Problem(cx, x[:, None], y[:, None], ms, max_batch=1)
+        lml, st = prob.lml([0], ms.theta()[None, :])
+        f, _, st2 = prob.value_grad([0], ms.unconstrain()[None, :])
+        prob.close()
+        assert st[0] == 0 and st2[0] == 0
+        got[name] = (lml[0], -f[0])
+    assert got["f64"][0] == pytest.approx(want, rel=1e-8) and got["f64"][1] == pytest.approx(want, rel=1e-8)
+    print(f"float32 vs the state-space likelihood at N = {N}: value-only {abs(got['f32'][0] - want) / abs(want):.1e}, "
+          f"value+gradient {abs(got['f32'][1] - want) / abs(want):.1e}")
+    assert got["f32"][0] == pytest.approx(want, rel=1e-4) and got["f32"][1] == pytest.approx(want, rel=1e-4)
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 65, 129])
 def test_f32_ragged_and_tiny_sizes(ctx32, ctx64, N):
     from waveome_amd.engine import Problem
