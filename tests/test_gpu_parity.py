@@ -879,7 +879,15 @@ def test_headline_objective_against_its_low_rank_closed_form_n2048(ctx):
     rng = np.random.default_rng(1)
     u = ms.unconstrain() + 0.3 * rng.normal(size=ms.n_trainable)
     f1, g1, st3 = prob.value_grad([3], u[None, :])
+    # where 40 L-BFGS-B iterations end, the loss and LML the FIT reports are the closed form's at the fitted parameters
+    from waveome_amd.engine import lbfgs_opts
+
+    fit = prob.fit(cols[:4], np.tile(ms.unconstrain(), (4, 1)), lbfgs_opts(maxiter=40, ftol=0.0, gtol=0.0))
     prob.close()
+    for c in range(4):
+        end = B.headline_closed_form(ms.constrain(fit["u"][c]), X, Y[c])
+        assert fit["lml"][c] == pytest.approx(end, rel=1e-9) and -fit["loss"][c] == pytest.approx(end, rel=1e-9)
+        assert end > want[c] + 100.0                 # (and the fit did climb: hundreds of nats above the start)
     assert st3[0] == 0
     assert -f1[0] == pytest.approx(B.headline_closed_form(ms.constrain(u), X, Y[3]), rel=1e-10)
     for k in (0, 1, 6, 7, 8, 15, 16):      # an SE variance and lengthscale; a Periodic variance, lengthscale, period; noise; mean
