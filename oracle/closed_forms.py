@@ -8,6 +8,7 @@ waveome_amd/.  Independent of gp_oracle.py: nothing here forms a Gram matrix or 
   low_rank_predict        posterior mean / variance of f at new rows for the same model (Bayesian linear regression in the features)
   headline_features       the (U, d) pair of the headline structure, shared feature count for training and new inputs
   headline_closed_form    BASELINE's headline structure sum_d (SE[d] + Periodic(SE)[d]) + Constant mean: rank ~650
+  spec_closed_form_grad   ... with exact derivatives for every variance parameter, the noise and the mean
   spec_features / spec_closed_form   ANY structure built from SE, Periodic, Lin, Poly, Constant, Categorical factors (sums of products)
   closed_form_lin_poly    Lin + Poly(degree 2) + Constant (waveome/kernels.py:19-32, 56-73)
   closed_form_periodic    Periodic(SE) + Lin
@@ -220,3 +221,56 @@ def spec_closed_form(spec, theta, X, y, max_rank=8000):
     U, d = spec_features(spec, theta, X, max_rank=max_rank)
     c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
     return low_rank_lml(U, d, theta[spec["noise"]], np.asarray(y, float) - c)
+
+
+def low_rank_lml_grad(U, d, s, y):
+    """(LML, dLML/dd [k], dLML/ds, dLML/dmean) for y ~ N(mean 1, U diag(d) U' + s I) at mean = 0 (pass y - mean).
+    With C = I + D G / s, G = U'U:  K_y^-1 U = U C^-1 / s, so  u_j' K_y^-1 u_j = (G C^-1)_jj / s  and  U' alpha = C^-T U'y / s."""
+    N, k = len(y), U.shape[1]
+    D = np.diag(np.asarray(d, float))
+    G = U.T @ U
+    C = np.eye(k) + D @ G / s
+    Cinv = np.linalg.inv(C)
+    Uy = U.T @ y
+    Ua = Cinv.T @ Uy / s                                   # U' alpha
+    alpha = (y - U @ (Cinv @ (D @ Uy)) / s) / s            # K_y^-1 y
+    logdet = N * np.log(s) + np.linalg.slogdet(C)[1]
+    lml = -0.5 * (y @ alpha) - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi)
+    quad_j = np.einsum("ij,ji->i", G, Cinv) / s            # u_j' K_y^-1 u_j
+    g_d = 0.5 * Ua * Ua - 0.5 * quad_j
+    tr_kinv = (N - np.trace(Cinv @ D @ G) / s) / s         # tr K_y^-1 = (N - tr(C^-1 D G) / s) / s
+    g_s = 0.5 * (alpha @ alpha) - 0.5 * tr_kinv
+    return lml, g_d, g_s, float(np.sum(alpha))
+
+
+def spec_closed_form_grad(spec, theta, X, y, max_rank=8000):
+    """(LML, gradient over ALL parameters with NaN where this form has no analytic derivative): exact derivatives with
+    respect to every kernel VARIANCE parameter (each feature weight is a monomial in them: its exponent is read off by
+    doubling the parameter), the noise variance and the Constant mean.  Lengthscales, periods and Poly offsets move the
+    features themselves - those entries are NaN; check them by central differences of `spec_closed_form`."""
+    theta = np.asarray(theta, float)
+    U, d = spec_features(spec, theta, X, max_rank=max_rank)
+    c = theta[spec["mean"]] if spec.get("mean") is not None else 0.0
+    lml, g_d, g_s, g_c = low_rank_lml_grad(U, d, theta[spec["noise"]], np.asarray(y, float) - c)
+    grad = np.full(len(theta), np.nan)
+    grad[spec["noise"]] = g_s
+    if spec.get("mean") is not None:
+        grad[spec["mean"]] = g_c
+    var_params = sorted({f["p"][0] for term in spec["terms"] for f in term if f["type"] != "empty"})
+    offsets = {f["p"][1] for term in spec["terms"] for f in term if f["type"] == "poly"}
+    for p in var_params:
+        if p in offsets:
+            continue
+        t2 = theta.copy()
+        t2[p] *= 2.0
+        d2 = _spec_weights(spec, t2, X)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            expo = np.where(d != 0, np.log2(d2 / d), 0.0)
+        grad[p] = float(np.sum(g_d * expo * d / theta[p]))
+    return lml, grad
+
+
+def _spec_weights(spec, theta, X):
+    """The weights of spec_features alone (the features do not depend on the variance parameters)."""
+    return spec_features(spec, theta, X)[1]
+

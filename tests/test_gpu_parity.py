@@ -890,7 +890,23 @@ def test_headline_objective_against_its_low_rank_closed_form_n2048(ctx):
         assert end > want[c] + 100.0                 # (and the fit did climb: hundreds of nats above the start)
     assert st3[0] == 0
     assert -f1[0] == pytest.approx(B.headline_closed_form(ms.constrain(u), X, Y[3]), rel=1e-10)
-    for k in (0, 1, 6, 7, 8, 15, 16):      # an SE variance and lengthscale; a Periodic variance, lengthscale, period; noise; mean
+    # gradient: exact from the closed form for the six variances, the noise and the mean (oracle/closed_forms.py::
+    # spec_closed_form_grad), central differences of the closed form for a lengthscale of each kind and the period
+    from oracle import closed_forms as CF
+
+    d = ms.to_dict()
+    t1 = ms.constrain(u)
+    lml_cf, gcf = CF.spec_closed_form_grad(d, t1, X, Y[3])
+    assert lml_cf == pytest.approx(-f1[0], rel=1e-10)
+    exact = 0
+    for k, i in enumerate(o.trainable_index(d)):
+        if np.isnan(gcf[i]):
+            continue
+        want_k = -gcf[i] * o.dconstrain_one(d["params"][i]["transform"], u[k])
+        assert g1[0][k] == pytest.approx(want_k, rel=1e-8, abs=1e-8 * np.max(np.abs(g1[0]))), (k, d["params"][i]["name"])
+        exact += 1
+    assert exact == 8
+    for k in (1, 7, 8):
         up, um = u.copy(), u.copy()
         up[k] += 1e-5
         um[k] -= 1e-5
@@ -1196,6 +1212,18 @@ def test_config_c3_composite_n4096(ctx):
     assert st1[0] == 0 and l1[0] == pytest.approx(closed_loss(u1), rel=1e-10)
     assert float(g1[0] @ dvec) == pytest.approx((closed_loss(u1 + h * dvec) - closed_loss(u1 - h * dvec)) / (2 * h),
                                                rel=1e-5, abs=1e-5)
+    # the gradient entries of the 17 trainable variance parameters, the noise and the mean: EXACT from the closed form
+    t1 = ms.constrain(u1)
+    _, gcf = CF.spec_closed_form_grad(d, t1, X, y)
+    gprior = o.log_prior_grad(d, t1)
+    checked = 0
+    for k, i in enumerate(o.trainable_index(d)):
+        if np.isnan(gcf[i]):
+            continue
+        want_k = -(gcf[i] + gprior[i]) * o.dconstrain_one(d["params"][i]["transform"], u1[k])
+        assert g1[0][k] == pytest.approx(want_k, rel=1e-7, abs=1e-7 * np.max(np.abs(g1[0]))), (k, d["params"][i]["name"])
+        checked += 1
+    assert checked == 19
     prob.close()
 
 

@@ -374,6 +374,34 @@ def test_random_low_rank_structures_against_their_closed_form():
     assert done >= 15
 
 
+def test_closed_form_gradient_of_the_variance_parameters():
+    """oracle/closed_forms.py::spec_closed_form_grad: exact derivatives of the Gram-free LML with respect to every
+    variance parameter, the noise and the mean - against the oracle's dense gradient on a full_kernel_build structure
+    (SE, Periodic, Lin base kernels, categorical x numeric products) and on Poly terms."""
+    from oracle import closed_forms as CF
+    from waveome_amd import ModelSpec, kernels as K
+    from waveome_amd.regularization import full_kernel_build
+
+    rng = np.random.default_rng(1)
+    N = 250
+    X = rng.normal(size=(N, 5))
+    X[:, 4] = rng.integers(0, 5, N)
+    y = np.sin(X[:, 0]) + 0.4 * (X[:, 4] == 2) + 0.2 * rng.normal(size=N)
+    kern = full_kernel_build(cat_vars=[4], num_vars=[0, 1, 2, 3], return_sum=True,
+                             kerns=[K.SquaredExponential(), K.Periodic(K.SquaredExponential()), K.Lin()])
+    poly = K.Sum([K.Poly(active_dims=[0], degree=3, variance=0.6, offset=0.7),
+                  K.Product([K.Categorical(active_dims=[4], variance=0.5), K.Poly(active_dims=[1], degree=2)])])
+    for kern_, n_exact in ((kern, 39), (poly, 5)):
+        ms = ModelSpec(kern_, 5, K.GaussianLikelihood(variance=0.3), K.ConstantMean(0.1))
+        d = ms.to_dict()
+        th = ms.constrain(ms.unconstrain() + 0.3 * rng.normal(size=ms.n_trainable))
+        lml, g = CF.spec_closed_form_grad(d, th, X, y)
+        lo, go = o.lml_and_grad(d, th, X, y)
+        ok = ~np.isnan(g)
+        assert ok.sum() == n_exact and lml == pytest.approx(lo, rel=1e-11)
+        np.testing.assert_allclose(g[ok], go[ok], rtol=1e-8, atol=1e-9 * np.max(np.abs(go)))
+
+
 def test_product_with_a_categorical_factor_is_one_independent_gp_per_level():
     """Categorical[g] * Matern32[x] (the unit x numeric / categorical x numeric terms of full_kernel_build,
     waveome/regularization.py:103-149) is block diagonal in the labels: its LML is the sum over the levels of the LML of
