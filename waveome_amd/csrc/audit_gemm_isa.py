@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Build-time audit of the compiled GEMM kernels that carry the hand-scheduled K loop (wv_gemm_kloop.inc).
+
+The accumulators live in AGPRs that the K-loop statements update in place while the compiler believes them unchanged
+between zero_acc and fence_acc (see gen_gemm_kloop.py).  That is only sound if, between those two statements, the
+compiler itself never touches an AGPR (and, for speed, never spills inside the K loop): this script reads the ISA hipcc produced (-save-temps .s) and
+fails the build otherwise.  It also reports registers, scratch and the loop's instruction mix."""
+import re
+import sys
+
+
+def kernels(text):
+    for m in re.finditer(r"^(_ZN2wv\S+):\s*; @\S+\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        yield m.group(1), m.group(2)
+
+
+def audit(path):
+    text = open(path).read()
+    bad = 0
+    for name, body in kernels(text):
+        if "WVACC" not in body:   # only the kernels that carry the hand-scheduled loop
+            continue
+        lines = body.split("\n")
+        inasm, blocks, cur = False, [], None
+        for k, l in enumerate(lines):
+            if "ASMSTART" in l:
+                inasm, cur = True, [k, None, []]
+            elif "ASMEND" in l:
+                inasm = False
+                cur[1] = k
+                blocks.append(cur)
+            elif inasm:
+                cur[2].append(l.strip())
+        zero = next((b for b in blocks if sum(x.startswith("v_accvgpr_write_b32") for x in b[2]) == 128), None)
+        fence = next((b for b in blocks if b[2] == ["s_nop 15"]), None)
+        if zero is None or fence is None:
+            print(f"AUDIT {name}: zero_acc / fence_acc not found")
+            bad += 1
+            continue
+        asm_lines = set()
+        for b in blocks:
+            asm_lines.update(range(b[0], b[1] + 1))
+        problems = []
+        first_loop_stmt = min(b[0] for b in blocks if b[0] > zero[1])
+        last_loop_stmt = max(b[1] for b in blocks if b[1] < fence[0])
+        for k in range(zero[1] + 1, fence[0]):
+            if k in asm_lines:
+                continue
+            code = lines[k].split(";")[0]
+            if "scratch_" in code and first_loop_stmt < k < last_loop_stmt:   # (a spill in the K loop: not wrong, but not acceptable)
+                problems.append((k, "scratch access", lines[k].strip()))
+            if re.search(r"v_accvgpr|[ ,\[]a\d+\b|\ba\[\d+:\d+\]", code):
+                problems.append((k, "compiler touches an AGPR", lines[k].strip()))
+        nscratch = sum("scratch_" in l.split(";")[0] for l in lines)
+        short = re.sub(r"^_ZN2wv15gemm_f64_kernelI|EEvNS_9GemmArgsTIdEE$", "", name)
+        print(f"audit <{short}>: {len(blocks)} asm statements, scratch ops in the kernel {nscratch}, "
+              f"inside the accumulator region {sum(p[1] == 'scratch access' for p in problems)}, "
+              f"compiler AGPR references inside it {sum(p[1] != 'scratch access' for p in problems)}")
+        for p in problems[:6]:
+            print("   ", p)
+        bad += len(problems) > 0
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if audit(sys.argv[1]) else 0)

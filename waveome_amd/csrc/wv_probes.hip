@@ -155,6 +155,40 @@ static int32_t dbg_gemm_bench_impl(wv_ctx* ctx, int32_t M, int32_t N, int32_t K,
 
 namespace wv { int read_gemm_stamps(unsigned long long* out); }
 
+// One launch of the float64 GEMM with the structure switches of the pipeline's products (lower-only tiles, trimmed
+// contraction ranges, transposed outputs), host matrices in and out: tools/check_gemm_asm.py compares the two K loops
+// bit for bit on every such form.  A: [nb][K][M] (K-strided) or [nb][M][K]; B: [nb][K][N]; C: [nb][M][N]; CT: [nb][N][M].
+extern "C" int32_t wv_dbg_gemm_ex(wv_ctx* ctx, const double* A, const double* B, double* C, double* CT, int32_t M, int32_t N,
+                                  int32_t K, int32_t a_kc, double alpha, double beta, int32_t nbatch, int32_t tri,
+                                  int32_t klo_mode, int32_t khi_mode, int32_t tout, int32_t tag, int32_t same_ab) {
+  if (!ctx || !A || !B || !C || !CT || ctx->c.dtype == 1) return WV_E_BADARG;
+  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  const size_t na = (size_t)M * K * nbatch, nbb = (size_t)N * K * nbatch, nc = (size_t)M * N * nbatch;
+  double *dA, *dB, *dC, *dCT;
+  WV_HIP_TRY(hipMalloc(&dA, 8 * na));
+  WV_HIP_TRY(hipMalloc(&dB, 8 * nbb));
+  WV_HIP_TRY(hipMalloc(&dC, 8 * nc));
+  WV_HIP_TRY(hipMalloc(&dCT, 8 * nc));
+  WV_HIP_TRY(hipMemcpy(dA, A, 8 * na, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(dB, B, 8 * nbb, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(dC, C, 8 * nc, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemcpy(dCT, CT, 8 * nc, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.A = dA; g.B = same_ab ? dA : dB; g.C = dC; g.CT = dCT;
+  g.sA = (int64_t)M * K; g.sB = same_ab ? g.sA : (int64_t)N * K; g.sC = (int64_t)M * N; g.sCT = (int64_t)M * N;
+  g.lda = a_kc ? K : M; g.ldb = same_ab ? g.lda : N; g.ldc = N; g.ldct = M;
+  g.M = M; g.N = N; g.kb = 0; g.ke = K; g.alpha = alpha; g.beta = beta; g.nbatch = nbatch;
+  g.tri = tri; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.tout = tout; g.tag = tag;
+  launch_gemm(nullptr, g, a_kc != 0, false, 128);
+  if (take_launch_failure()) return WV_E_UNSUPPORTED;
+  WV_HIP_TRY(hipGetLastError());
+  WV_HIP_TRY(hipDeviceSynchronize());
+  WV_HIP_TRY(hipMemcpy(C, dC, 8 * nc, hipMemcpyDeviceToHost));
+  WV_HIP_TRY(hipMemcpy(CT, dCT, 8 * nc, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCT);
+  return WV_OK;
+}
+
 extern "C" {
 
 /* shader-clock stamps of workgroup 0 of the last small-tile GEMM launch: entry, first chunk in LDS, end of the K loop, end */
