@@ -431,6 +431,23 @@ def main():
         dist.all_gather(allb, mine)   # report the imbalance (max / mean rank time)
         rank_busy = [float(b.item()) for b in allb]
     dom_stage = prob.stage_times()[DOMINANT_STAGE]
+    # Strong scaling ("headline: 512 -> 64 / GPU"; the reference's Ray rounds, waveome/model_search.py:
+    # 474-489): ONE extra, untimed step in which the 512 headline fits are split over the ranks - 512 // world fits per
+    # GPU, all in flight at once.  Outside the timed region; steps / warmup / the weak-scaling value are untouched.
+    strong = None
+    if distributed and world > 1:
+        sc = parallel.shard_tasks(min(P, 512), rank, world).astype(np.int32)
+        barrier()
+        t_s = time.perf_counter()
+        r_s = prob.fit(sc, np.tile(spec.unconstrain(), (len(sc), 1)), opts)
+        barrier()
+        t_s = time.perf_counter() - t_s
+        tt = torch.tensor([t_s, float(r_s["nit"].sum()) / 100.0], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        tmx = tt.clone()
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        strong = {"fits": float(tt[1].item()), "seconds": float(tmx[0].item()), "fits_per_gpu": int(len(sc)),
+                  "fits_per_s": float(tt[1].item()) / float(tmx[0].item())}
     stages = None
     wall_used = time.perf_counter() - T_PROCESS_START
     if rank == 0 and not distributed and not args.no_breakdown and wall_used < WALL_BUDGET_S - 60:
@@ -461,6 +478,8 @@ def main():
                                    "(profiles/r03_fit_trajectory_parity.txt), and is credited pro rata (iterations / 100)",
                        "fits_per_gpu_per_step": args.tasks, "fits_in_flight_per_gpu": args.batch,
                        "parallelism": f"task-sharded x{world}", "all_fits_ran_100_iterations": nit_ok,
+                       "strong_scaling_fits_per_s": None if strong is None else strong["fits_per_s"],
+                       "strong_scaling": strong,
                        "rank_fit_seconds": [round(v, 3) for v in rank_busy],
                        "rank_time_max_over_mean": float(max(rank_busy) / (sum(rank_busy) / len(rank_busy))),
                        "mean_evals_per_fit": float(table[:, 3].mean()),

@@ -34,6 +34,9 @@ if backend:
     assert parallel.collective_device().type == ("cuda" if backend == "nccl" else "cpu")
 from waveome_amd import kernels as K
 from waveome_amd.model_search import GPSearch
+if os.environ.get("WV_SMALL_CAPS"):   # structures beyond a search session's capacities: the blocking fallback fires
+    from waveome_amd import kernel_search as ks
+    ks._SearchSession.CAPS = dict(ks._SearchSession.CAPS, max_params=int(os.environ["WV_SMALL_CAPS"]))
 rng = np.random.default_rng(3)
 n = 60
 X = pd.DataFrame({"t": rng.normal(size=n), "dose": rng.normal(size=n), "grp": (np.arange(n) % 3).astype(float)})
@@ -110,3 +113,25 @@ def test_one_rank_over_rccl_reproduces_the_single_process_results(tmp_path):
     assert got["pen"] == single["pen"]
     np.testing.assert_array_equal(got["sweep"], single["sweep"])
     assert got["search"] == single["search"] and got["best"] == single["best"]
+
+
+def test_sharded_search_with_a_structure_beyond_the_session_capacities(tmp_path):
+    """in the unsynchronised sharded search a structure that exceeds the session's capacities is scored
+    through the blocking path - on the one rank that met it, so that path must not enter a collective (it used to:
+    `parallel.dynamic_map`, unmatched on the other rank).  With the capacity lowered so that every product structure
+    of the search takes the fallback, two ranks must finish and reproduce the single-process trees."""
+    out = str(tmp_path / "res")
+    caps = {"WV_SMALL_CAPS": "5"}
+    p = _run(caps, out)
+    log, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, log.decode()[-3000:]
+    port = _free_port()
+    procs = [_run(dict(caps, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), WV_BACKEND="gloo"), out) for r in range(2)]
+    for q in procs:
+        log, _ = q.communicate(timeout=600)
+        assert q.returncode == 0, log.decode()[-3000:]
+    single = pickle.load(open(out + ".s", "rb"))
+    for r in range(2):
+        got = pickle.load(open(out + f".{r}", "rb"))
+        assert got["search"] == single["search"] and got["best"] == single["best"]

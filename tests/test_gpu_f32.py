@@ -146,7 +146,8 @@ def test_set_precision_switches_the_default_context():
 
     with pytest.raises(ValueError):
         U.set_precision("float16")
-    U.set_precision("float32")
+    with pytest.warns(UserWarning, match="throughput mode"):   # float32 says what it is
+        U.set_precision("float32")
     try:
         assert U.get_precision() == "float32" and default_context().dtype == "float32"
     finally:

@@ -1729,7 +1729,8 @@ U = spec.unconstrain()[None, :] + 0.2 * rng.normal(size=(3, spec.n_trainable))
 cols = np.arange(3, dtype=np.int32)
 f, g, st = p.value_grad(cols, U)
 th = spec.constrain(U[0])
-np.savez(sys.argv[2], f=f, g=g, st=st, M=p.dbg_stage(0, th, 1), Kinv=p.dbg_stage(0, th, 2), X=X, Y=Y, U=U)
+lml, _ = p.lml(cols, np.stack([spec.constrain(U[t]) for t in range(3)]))
+np.savez(sys.argv[2], f=f, g=g, st=st, M=p.dbg_stage(0, th, 1), Kinv=np.tril(p.dbg_stage(0, th, 2)), X=X, Y=Y, U=U, lml=lml)
 """
 
 
@@ -1746,15 +1747,27 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
     script = tmp_path / "regime.py"
     script.write_text(_TILE_REGIME_SCRIPT)
     outs = {}
-    for name, extra in (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
-                        ("unpaired", {"WV_PAIR": "0"})):  # (trailing update and T as two launches instead of one)
+    # every switch of the release library that selects between kernels / schedules (waveome_amd/csrc/README.md), one at
+    # a time and the tile switches combined: same bits.  (The 128-wide tiles run the hand-scheduled K loop, the small
+    # tile and the diagonal-tile launches hipcc's: the two also have to agree to the bit.)
+    variants = (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
+                ("unpaired", {"WV_PAIR": "0"}),  # (trailing update and T as two launches instead of one)
+                ("wide, one launch per lower-only product", {"WV_BN_FILL": "0", "WV_TRI_SPLIT": "0"}),
+                ("128 x 64 tiles", {"WV_SMALL_FILL": "0"}), ("64-wide leaves", {"WV_LEAF128": "0"}),
+                ("two batch groups", {"WV_GROUPS": "2"}), ("no block tables", {"WV_BLOCKS": "0"}),
+                ("value through factor + inverse", {"WV_VALUE_FULL": "1"}), ("host trace", {"WV_FIT_TRACE": "1"}))
+    for name, extra in variants:
         env = dict(os.environ, **extra)
-        out = tmp_path / f"{name}.npz"
-        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
+        out = tmp_path / f"{name.replace(' ', '_').replace(',', '')}.npz"
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600,
+                       stderr=subprocess.DEVNULL if "WV_FIT_TRACE" in extra else None)
         outs[name] = np.load(out)
     a = outs["default"]
-    for other in ("wide", "unpaired"):
-        for key in ("f", "g", "M", "Kinv"):
+    for other, _ in variants[1:]:
+        for key in ("f", "g", "M", "Kinv", "lml"):
+            if key == "lml" and other == "value through factor + inverse":  # (another schedule: rounding, not bits)
+                np.testing.assert_allclose(a[key], outs[other][key], rtol=1e-12, err_msg=f"{other}: {key}")
+                continue
             np.testing.assert_array_equal(a[key], outs[other][key], err_msg=f"{other}: {key}")
     assert np.all(a["st"] == 0)
     kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),

@@ -48,8 +48,19 @@ def test_release_library_carries_no_experiments(lib):
     for name in sorted(probes):
         assert not hasattr(lib, name), f"{name} is a probe and must not be in the release library"
     blob = open(_lib.LIB_PATH, "rb").read()
-    for switch in (b"WV_GEMM_DBG", b"WV_ROT_TRI", b"WV_GEMM_OCC", b"WV_GEMM_LATIN"):
+    for switch in (b"WV_GEMM_DBG", b"WV_ROT_TRI", b"WV_GEMM_OCC", b"WV_GEMM_LATIN", b"WV_GEMM_ASM", b"WV_GEMM_LDS_PAD"):
         assert switch not in blob, switch
+    # every environment switch the release library can read is on the documented list (csrc/README.md; each one is
+    # exercised by tests/test_gpu_parity.py::test_every_tile_regime_gives_the_same_bits); WV_MAX_PARAMS is the name of
+    # a limit in an error message, not a switch
+    documented = {b"WV_GROUPS", b"WV_BN_FILL", b"WV_SMALL_FILL", b"WV_PAIR", b"WV_TRI_SPLIT", b"WV_TRI_SPLIT_MIN",
+                  b"WV_LEAF128", b"WV_BLOCKS", b"WV_VALUE_FULL", b"WV_FIT_TRACE"}
+    import re
+    found = set(re.findall(rb"WV_[A-Z0-9_]+", blob)) - {b"WV_MAX_PARAMS"}
+    assert found == documented, (sorted(found - documented), sorted(documented - found))
+    readme = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "README.md")).read()
+    for name in documented:
+        assert name.decode() in readme, f"{name.decode()} is not documented in waveome_amd/csrc/README.md"
 
 
 def test_no_gpu_fails_loudly_not_silently(lib):
@@ -408,7 +419,8 @@ def test_precision_switch_validates_its_argument():
         U.set_precision("float16")
     with pytest.raises(ValueError):
         Context(0, dtype="bfloat16")
-    U.set_precision("float32")
+    with pytest.warns(UserWarning, match="throughput mode"):   # float32 says what it is: ~1e-4 on the loss, not 1e-6
+        U.set_precision("float32")
     assert U.get_precision() == "float32"
     U.set_precision("float64")
 

@@ -1,0 +1,94 @@
+"""Converged-fit parity where the metric is quoted: bench columns (N = 2048, headline structure)
+fitted with the REFERENCE's options - maxiter = maxfun = 50000 and SciPy's default ftol / gtol
+(waveome/model_classes.py:310-334) - by SciPy L-BFGS-B on the CPU oracle and by the device, then compared at the
+optimum: LML / loss, fitted hyper-parameters, the gradient's infinity norm at both end points, and each side's
+objective at the other's end point.
+
+Two steps, because the oracle fits take tens of CPU minutes and need no GPU:
+  python tools/converged_fit_parity.py scipy [columns...]   -> profiles/r04_converged_fit_scipy.json   (CPU only)
+  python tools/converged_fit_parity.py gpu                  -> the table (GPU box; reads the JSON above)
+A checker, not product code: this is one of the places allowed to import oracle/."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.optimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from oracle import gp_oracle as o  # noqa: E402
+
+JSON = os.path.join(ROOT, "profiles", "r04_converged_fit_scipy.json")
+DEFAULT_COLS = [0, 456, 31, 246, 100, 300]
+P = 512
+
+
+def scipy_side(cols):
+    X, Y = bench.make_inputs(P)
+    spec = bench.headline_spec()
+    d = spec.to_dict()
+    u0 = spec.unconstrain()
+    out = json.load(open(JSON)) if os.path.exists(JSON) else {}
+    for c in cols:
+        if str(c) in out:
+            continue
+        t0 = time.perf_counter()
+        res = scipy.optimize.minimize(lambda u: o.objective(d, u, X, Y[c]), u0, jac=True, method="L-BFGS-B",
+                                      options=dict(maxiter=50000, maxfun=50000, maxcor=10, maxls=20))  # default ftol / gtol
+        f, g = o.objective(d, res.x, X, Y[c])
+        out[str(c)] = dict(u=res.x.tolist(), loss=float(res.fun), nit=int(res.nit), nfev=int(res.nfev), message=str(res.message),
+                           ginf=float(np.max(np.abs(g))), seconds=time.perf_counter() - t0, scipy=scipy.__version__)
+        print(f"column {c}: {res.nit} iterations, {res.nfev} evaluations, loss {res.fun:.10f}, |g|inf {np.max(np.abs(g)):.2e}, "
+              f"{res.message}, {time.perf_counter() - t0:.0f} s", flush=True)
+        json.dump(out, open(JSON, "w"), indent=1)
+
+
+def gpu_side():
+    from waveome_amd.engine import Context, Problem, lbfgs_opts
+
+    ref = json.load(open(JSON))
+    cols = sorted(int(c) for c in ref)
+    X, Y = bench.make_inputs(P)
+    spec = bench.headline_spec()
+    d = spec.to_dict()
+    u0 = spec.unconstrain()
+    ctx = Context(0)
+    prob = Problem(ctx, X, Y.T, spec, max_batch=len(cols))
+    ci = np.array(cols, dtype=np.int32)
+    res = prob.fit(ci, np.tile(u0, (len(cols), 1)), lbfgs_opts(maxiter=50000, maxfun=50000))   # SciPy's default ftol / gtol
+    Ud = res["u"]
+    Us = np.array([ref[str(c)]["u"] for c in cols])
+    f_dd, g_dd, _ = prob.value_grad(ci, Ud)       # device objective at the device's end points
+    f_ds, g_ds, _ = prob.value_grad(ci, Us)       # ... at SciPy's
+    npar = len(u0)
+    lml_const = 0.0                               # the headline structure has no priors: loss = -LML
+    print("# bench columns (N = 2048, headline structure, 17 parameters), reference options: maxiter = maxfun = 50000, SciPy default ftol = 2.2e-9, gtol = 1e-5")
+    print("# column | device: nit nfev status loss |g|inf | SciPy on the oracle: nit nfev loss |g|inf | rel. LML gap | max rel. parameter gap | "
+          "device objective at SciPy's end point - SciPy's loss | oracle objective at the device's end point - device's loss")
+    worst = 0.0
+    for k, c in enumerate(cols):
+        r = ref[str(c)]
+        f_od, g_od = o.objective(d, Ud[k], X, Y[c])
+        th_d, th_s = spec.constrain(Ud[k]), spec.constrain(Us[k])
+        gap = abs(res["loss"][k] - r["loss"]) / abs(r["loss"])
+        pgap = np.max(np.abs(th_d - th_s) / np.maximum(np.abs(th_s), 1e-12))
+        worst = max(worst, gap)
+        print(f"{c:6d} | {int(res['nit'][k]):5d} {int(res['nfev'][k]):5d} {int(res['status'][k]):2d} {res['loss'][k]:.10f} {np.max(np.abs(g_dd[k])):.2e} | "
+              f"{r['nit']:5d} {r['nfev']:5d} {r['loss']:.10f} {r['ginf']:.2e} | {gap:.2e} | {pgap:.2e} | {f_ds[k] - r['loss']:+.2e} | {f_od - res['loss'][k]:+.2e}"
+              f"   (|g_device(SciPy end)|inf {np.max(np.abs(g_ds[k])):.2e}; {r['message']})", flush=True)
+        print(f"         theta device {np.array2string(th_d, precision=6, max_line_width=250)}")
+        print(f"         theta SciPy  {np.array2string(th_s, precision=6, max_line_width=250)}")
+    print(f"# worst relative LML gap {worst:.2e} (north star: 1e-6)")
+    prob.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "scipy":
+        scipy_side([int(a) for a in sys.argv[2:]] or DEFAULT_COLS)
+    else:
+        gpu_side()

@@ -2,8 +2,8 @@
 """Build-time audit of the compiled GEMM kernels that carry the hand-scheduled K loop (wv_gemm_kloop.inc).
 
 The accumulators live in AGPRs that the K-loop statements update in place while the compiler believes them unchanged
-between zero_acc and fence_acc (see gen_gemm_kloop.py).  That is only sound if, between those two statements, the
-compiler itself never touches an AGPR (and, for speed, never spills inside the K loop): this script reads the ISA hipcc produced (-save-temps .s) and
+from zero_acc on (see gen_gemm_kloop.py) and only asm statements ever read them.  That is only sound if the compiler
+itself never touches an AGPR in these kernels (and, for speed, never spills inside the K loop): this script reads the ISA hipcc produced (-save-temps .s) and
 fails the build otherwise.  It also reports registers, scratch and the loop's instruction mix."""
 import re
 import sys
@@ -32,17 +32,18 @@ def audit(path):
             elif inasm:
                 cur[2].append(l.strip())
         zero = next((b for b in blocks if sum(x.startswith("v_accvgpr_write_b32") for x in b[2]) == 128), None)
-        fence = next((b for b in blocks if b[2] == ["s_nop 15"]), None)
-        if zero is None or fence is None:
-            print(f"AUDIT {name}: zero_acc / fence_acc not found")
+        loop_stmts = [b for b in blocks if any(x.startswith("v_mfma") for x in b[2])]
+        if zero is None or not loop_stmts:
+            print(f"AUDIT {name}: zero_acc / K-loop statements not found")
             bad += 1
             continue
+        fence = [len(lines), len(lines), []]   # the accumulators are live to the end of the kernel (read-out statements)
         asm_lines = set()
         for b in blocks:
             asm_lines.update(range(b[0], b[1] + 1))
         problems = []
-        first_loop_stmt = min(b[0] for b in blocks if b[0] > zero[1])
-        last_loop_stmt = max(b[1] for b in blocks if b[1] < fence[0])
+        first_loop_stmt = min(b[0] for b in loop_stmts)
+        last_loop_stmt = max(b[1] for b in loop_stmts)
         for k in range(zero[1] + 1, fence[0]):
             if k in asm_lines:
                 continue

@@ -16,6 +16,26 @@
 
 namespace wv {
 
+// The environment switches of the release library (see wv_device.hpp).  Every one selects between paths that give the
+// same bits (tests/test_gpu_parity.py::test_every_switch_of_the_release_library_gives_the_same_bits) except where noted.
+static const char* const kTuningSwitches[] = {
+    "WV_GROUPS",         // batch groups (streams) the fits in flight are split over; default 1
+    "WV_BN_FILL",        // tiles a launch needs for the 128 x 128 tiling (default 4096)
+    "WV_SMALL_FILL",     // ... for the 128 x 64 tiling before the small 64 x 64 tile (default 8192)
+    "WV_PAIR",           // 0: trailing update and T as two launches instead of one (few fits in flight)
+    "WV_TRI_SPLIT",      // 0: lower-only products as one launch (no diagonal-tile launch)
+    "WV_TRI_SPLIT_MIN",  // diagonal tiles a launch needs to get its own diagonal-tile launch (default 256)
+    "WV_LEAF128",        // 0: 64-wide leaves and their products instead of the fused 128-node
+    "WV_BLOCKS",         // 0: no zero-block skipping (dense products on block-diagonal structures)
+    "WV_VALUE_FULL",     // value-only evaluations through factor + inverse (same LML to rounding, not to the bit)
+    "WV_FIT_TRACE",      // host-side timing of a fit loop on stderr (no effect on results)
+};
+const char* tuning_env(const char* name) {
+  for (const char* s : kTuningSwitches)
+    if (std::strcmp(s, name) == 0) return std::getenv(name);
+  return nullptr;
+}
+
 const char* const kStageNames[ST_COUNT] = {
     "gram_assembly", "potrf_diag", "chol_trsm", "chol_panel_update", "chol_trailing_syrk",
     "trtri_tri_gemm", "trtri_diag_gemm", "lauum_gemm", "solve_matvec", "grad_trace", "reduce",
@@ -151,8 +171,8 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
     WV_HIP_TRY(hipMemcpyAsync(p.dslotspec + g.slot0, g.h_spec, sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
   launch_resid(p, st, g.slot0, nb);
   launch_gram(p, st, g.slot0, nb, 0);
-  static const bool old_sched = std::getenv("WV_SCHED_OLD") != nullptr;
-  static const bool full_value = std::getenv("WV_VALUE_FULL") != nullptr;  // value-only through factor + inverse
+  static const bool old_sched = experiment_env("WV_SCHED_OLD") != nullptr;  // (round 1's right-looking schedule)
+  static const bool full_value = tuning_env("WV_VALUE_FULL") != nullptr;   // value-only through factor + inverse
   if (old_sched) {
     cholesky(p, st, g.slot0, nb);
     trtri(p, st, g.slot0, nb);
@@ -524,7 +544,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
   WV_HIP_TRY(hipMemset(p.dslotspec, 0, sizeof(int32_t) * max_batch));
   WV_HIP_TRY(hipMemset(p.dspec_span, 0xff, sizeof(int32_t) * p.spec_cap));  // -1: dense
   {
-    const char* e = std::getenv("WV_BLOCKS");
+    const char* e = tuning_env("WV_BLOCKS");
     if (!(e && std::atoi(e) == 0) && !p.f32) {  // (the float32 GEMM does not read the tables)
       p.hX.resize((size_t)N * D);
       WV_HIP_TRY(hipMemcpy(p.hX.data(), X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
@@ -540,7 +560,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
   // 3500 - large launches amortise the serial small kernels better than cross-stream overlap does -
   // so the default is a single group; WV_GROUPS overrides.
   int ng = 1;
-  if (const char* s = std::getenv("WV_GROUPS")) ng = std::max(1, std::atoi(s));
+  if (const char* s = tuning_env("WV_GROUPS")) ng = std::max(1, std::atoi(s));
   ng = std::min(ng, max_batch);
   int base = max_batch / ng, extra = max_batch % ng, at = 0;
   p.groups.resize(ng);
@@ -564,7 +584,11 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     p.quad_stride = 64 * (int64_t)std::max(1, p.max_red);
     p.quad_fits = std::min(FEW_FITS, base + (extra ? 1 : 0));
     const size_t bytes = sizeof(double) * (size_t)ng * p.quad_fits * p.ntiles() * p.quad_stride;
-    if (bytes > ((size_t)8 << 30) || hipMalloc((void**)&p.dquad, bytes) != hipSuccess) {
+    // (an optional buffer must not be what exhausts the device: at most an eighth of what is still free - at
+    //  N ~ 98304 it would be ~4 GB on top of a workspace that nearly fills the 288 GB)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    if (bytes > ((size_t)8 << 30) || bytes > free_b / 8 || hipMalloc((void**)&p.dquad, bytes) != hipSuccess) {
       (void)hipGetLastError();
       p.dquad = nullptr;
     } else {
@@ -947,7 +971,7 @@ static int32_t fit_impl(wv_problem* h, const int32_t* col_idx, const int32_t* sp
     task.u0.assign(u0, u0 + p.specs[task.spec].n_trainable());
     q.submit(std::move(task));
   }
-  const bool trace = std::getenv("WV_FIT_TRACE") != nullptr;
+  const bool trace = tuning_env("WV_FIT_TRACE") != nullptr;
   const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   while (q.in_system() > 0) {
     rc = q.advance();
@@ -1266,10 +1290,10 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
 // Kbuf(lower) = I + Mbuf(lower) * inv_s2   (the whitened posterior precision I + L'L / sigma^2 from L'L in Mbuf)
 __global__ __launch_bounds__(256) void precision_kernel(double* __restrict__ Kmat, const double* __restrict__ LtL,
                                                         int64_t Npad, double inv_s2) {
-  const int64_t i = blockIdx.y;
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j > i || j >= Npad) return;
-  Kmat[i * Npad + j] = LtL[i * Npad + j] * inv_s2 + (i == j ? 1.0 : 0.0);
+  // (rows on grid.x: grid.y stops at 65535 and a problem may have more rows than that)
+  const int64_t i = blockIdx.x;
+  for (int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x; j <= i; j += (int64_t)gridDim.y * 256)
+    Kmat[i * Npad + j] = LtL[i * Npad + j] * inv_s2 + (i == j ? 1.0 : 0.0);
 }
 
 int32_t wv_whitened_state(wv_problem* h, int32_t col, const double* theta, double jitter, double* q_mu_out,
@@ -1324,8 +1348,8 @@ int32_t wv_whitened_state(wv_problem* h, int32_t col, const double* theta, doubl
     a.alpha = 1.0; a.beta = 0.0; a.nbatch = 1;
     a.tri = 1; a.tri_off = 0;
     launch_gemm(st, a, false, false, 64);
-    hipLaunchKernelGGL(precision_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, K0, M0, Np,
-                       1.0 / s2);
+    hipLaunchKernelGGL(precision_kernel, dim3((unsigned)Np, (unsigned)std::min<int64_t>((Np + 255) / 256, 256)), dim3(256), 0,
+                       st, K0, M0, Np, 1.0 / s2);
     // (I + L'L / sigma^2)^-1 by the factor-and-invert pipeline of the fits, then its Cholesky factor
     factor_inverse(p, st, g.slot0, 1);
     lauum(p, st, g.slot0, 1);

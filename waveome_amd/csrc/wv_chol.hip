@@ -982,8 +982,8 @@ void trtri(Problem& p, hipStream_t st, int slot0, int nb) {
 // window left (WV_SMALL_FILL = 2 x WV_BN_FILL); WV_BN_FILL=0 restores 128 x 128 everywhere, WV_SMALL_FILL=0 stops at
 // 128 x 64.
 static int pick_bn(int64_t rows, int64_t cols, int nb, bool lower_only) {
-  static const int fill = [] { const char* e = getenv("WV_BN_FILL"); return e ? atoi(e) : 4096; }();
-  static const int small_fill = [] { const char* e = getenv("WV_SMALL_FILL"); return e ? atoi(e) : 8192; }();
+  static const int fill = [] { const char* e = tuning_env("WV_BN_FILL"); return e ? atoi(e) : 4096; }();
+  static const int small_fill = [] { const char* e = tuning_env("WV_SMALL_FILL"); return e ? atoi(e) : 8192; }();
   int64_t tiles = ((rows + 127) / 128) * ((cols + 127) / 128);
   if (lower_only) tiles = (tiles + (rows + 127) / 128) / 2;
   if (tiles * nb >= fill) return cols <= 64 ? 64 : 128;
@@ -1005,7 +1005,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     launch_potrf_diag(p, st, slot0, nb, (int)o);
     return;
   }
-  static const bool fuse128 = [] { const char* e = getenv("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
+  static const bool fuse128 = [] { const char* e = tuning_env("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
   if (n == 2 * NB && fuse128) {  // the whole node in one kernel
     launch_potrf128(p, st, slot0, nb, (int)o);
     return;
@@ -1051,7 +1051,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   bool paired = false;
   if constexpr (std::is_same<R, double>::value) {
     // few fits in flight (both products on 64-wide or small tiles): ONE launch runs them side by side
-    static const bool pair_ok = [] { const char* e = getenv("WV_PAIR"); return e ? atoi(e) != 0 : true; }();
+    static const bool pair_ok = [] { const char* e = tuning_env("WV_PAIR"); return e ? atoi(e) != 0 : true; }();
     if (pair_ok && tile_su <= 64 && tile_tp <= 64) {
       p.timer.begin(st, ST_CHOL_TRAIL);
       launch_gemm_pair(st, su, tp, std::min(tile_su, tile_tp));
@@ -1108,7 +1108,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     return;
   }
-  static const bool fuse128 = [] { const char* e = getenv("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
+  static const bool fuse128 = [] { const char* e = tuning_env("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
   if (n == 2 * NB && fuse128) {  // fused node: M of the whole 128 block is available, one forward substitution
     launch_potrf128(p, st, slot0, nb, (int)o);
     p.timer.begin(st, ST_SOLVE);
@@ -1183,7 +1183,7 @@ static void lauum_t(Problem& p, hipStream_t st, int slot0, int nb) {
   // 128-wide tiles (its own kernel symbols <..., 0, 1> and, for the diagonal-tile launch, <..., 0, 5>) unless so few
   // fits are in flight that a few long tiles are the cost: then the small tile, one launch (timed as its own stage, so
   // that ST_LAUUM's launches are exactly those of the two named symbols)
-  static const int forced = [] { const char* e = getenv("WV_LAUUM_TILE"); return e ? atoi(e) : 0; }();  // (experiments)
+  static const int forced = [] { const char* e = experiment_env("WV_LAUUM_TILE"); return e ? atoi(e) : 0; }();  // (experiments)
   const int tile = forced ? forced : pick_bn(Np, Np, nb, true);
   const int stage = tile == 128 ? ST_LAUUM : ST_LAUUM_FEW;
   p.timer.begin(st, stage);

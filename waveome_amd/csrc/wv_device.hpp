@@ -15,6 +15,7 @@
 // log|K_y|, r' K_y^-1 r and the leading N x N block of K_y^-1 are unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdint>
@@ -208,6 +209,19 @@ struct Problem {
 
 // result record layout per slot: [0]=lml, [1]=quad(z'z), [2]=logdet, [3..3+n_params)=dLML/dtheta
 inline int out_stride_for(int n_params) { return 3 + n_params; }
+
+// ---- environment switches --------------------------------------------------------------
+// The release library reads exactly the switches of kTuningSwitches (wv_api.hip; documented one by one in
+// waveome_amd/csrc/README.md, each covered by a bit-identity test in tests/test_gpu_parity.py): tuning_env() returns
+// nullptr for any other name.  experiment_env() is for everything that only exists to measure an alternative: it reads the
+// environment in the diagnostic build (-DWV_EXPERIMENTS) and is the constant nullptr in the release library, which
+// therefore does not even contain those names.
+const char* tuning_env(const char* name);
+#ifdef WV_EXPERIMENTS
+inline const char* experiment_env(const char* name) { return std::getenv(name); }
+#else
+#define experiment_env(name) (static_cast<const char*>(nullptr))
+#endif
 
 // ---- kernel launchers (each enqueues on `st`, no host sync) ---------------------------
 void launch_gram(Problem& p, hipStream_t st, int slot0, int nb, int write_upper);

@@ -818,9 +818,9 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
   hipLaunchKernelGGL((gram_kernel<R, MA, MU>), grid, blk, gram_lds_bytes(p), st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, \
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask, \
                      diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
-  static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
+  static const bool force_multi = [] { const char* e = experiment_env("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   // (measured, 512 fits at N = 2048, same box: 7.02 ms at 3 waves per SIMD, 6.69 at 4 with 31 VGPRs spilled)
-  static const int waves = [] { const char* e = getenv("WV_GRAM_WAVES"); return e ? atoi(e) : 4; }();
+  static const int waves = [] { const char* e = experiment_env("WV_GRAM_WAVES"); return e ? atoi(e) : 4; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.dmask) {
     if (multi) { WV_GRAM_LAUNCH(true, true); } else { WV_GRAM_LAUNCH(true, false); }
@@ -886,11 +886,11 @@ static void trace_launch(Problem& p, hipStream_t st, const RT* kbuf, int slot0, 
 
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   p.timer.begin(st, ST_TRACE);
-  static const bool force_multi = [] { const char* e = getenv("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
+  static const bool force_multi = [] { const char* e = experiment_env("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
   // (512 fits at N = 2048, same box: general kernel 7.4 ms; without the product paths 7.03 at 3 waves per SIMD - 140
   // VGPRs, nothing spilled - and 6.68 at 4 waves - 128 VGPRs, 10 spilled; WV_TRACE_WAVES=3 selects the former)
-  static const int waves = [] { const char* e = getenv("WV_TRACE_WAVES"); return e ? atoi(e) : 4; }();
+  static const int waves = [] { const char* e = experiment_env("WV_TRACE_WAVES"); return e ? atoi(e) : 4; }();
   if (!p.f32 && !multi && !p.any_product && !p.dmask) {  // sums of single-column factors, float64, no missing outputs
     if (waves == 4) trace_launch<double, false, false, false, true>(p, st, p.Kbuf, slot0, nb);
     else trace_launch<double, false, false, false, false>(p, st, p.Kbuf, slot0, nb);

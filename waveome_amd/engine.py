@@ -250,15 +250,15 @@ class Problem:
         queue (wv_queue_*) is topped up from `pull()` whenever fewer than `max_batch + backlog` tasks are queued or in
         flight.  `pull()` -> array of task ids (empty: nothing left; e.g. parallel.TaskDealer.pull, which deals chunks
         to the ranks of a job on demand); `task_args(ids)` -> (cols, spec_idx, U0, prior_scale or None) for those ids.
-        `first_fill` (parallel.TaskDealer.first_fill): never hold more than this many tasks - a rank of a small job must
-        not grab more than its share before anything has finished.
+        `first_fill` (parallel.TaskDealer.first_fill): hold no more than this many tasks until the first fit has
+        finished - a rank of a small job must not grab more than its share before anything has come back.
         Returns (ids, dict of arrays like fit_multi's) in the order the tasks were drawn.  Fits are bit-identical to
         fit / fit_multi on the same tasks (a slot's arithmetic does not depend on what else is in the batch)."""
         width = int(width or max(sp.n_trainable for sp in self.specs))
         backlog = self.max_batch // 4 if backlog is None else int(backlog)
-        hold = self.max_batch + max(0, backlog)
-        if first_fill is not None:
-            hold = max(1, min(hold, int(first_fill)))
+        hold_full = self.max_batch + max(0, backlog)
+        # (the first-fill bound holds until the first fit has come back; afterwards the queue may fill up)
+        hold = hold_full if first_fill is None else max(1, min(hold_full, int(first_fill)))
         q = FitQueue(self, opts, width=width)
         drawn, got, spec_of = [], {}, {}
         exhausted = False
@@ -280,6 +280,7 @@ class Problem:
                     continue
                 done, _ = q.advance()
                 if done:
+                    hold = hold_full
                     r = q.fetch(max(done, 64))
                     for j, tg in enumerate(r["tag"]):
                         got[int(tg)] = (r["u"][j].copy(), r["loss"][j], r["lml"][j], r["nit"][j], r["nfev"][j],

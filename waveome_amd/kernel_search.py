@@ -414,8 +414,13 @@ class GpuScorer:
     def _spec(self, kernel) -> ModelSpec:
         return ModelSpec(kernel, self.X.shape[1], K.GaussianLikelihood(), K.ConstantMean())
 
-    def __call__(self, tasks: List[tuple]) -> List[Optional[dict]]:
-        """tasks: [(column, kernel)] -> [fit dict or None] in the same order."""
+    def __call__(self, tasks: List[tuple], local: bool = False) -> List[Optional[dict]]:
+        """tasks: [(column, kernel)] -> [fit dict or None] in the same order.
+
+        `local`: score on THIS rank only, no `parallel.*` call - for callers that are not in lock step with the other
+        ranks (the unsynchronised sharded search's fallback for a structure beyond its session's capacities: only the
+        one rank gets there, so a collective would be unmatched and the job would hang or pair with another rank's
+        later gather)."""
         from .engine import Problem
         from .model_search import _default_batch
 
@@ -542,7 +547,9 @@ class GpuScorer:
         if order:
             rank, world = parallel.dist_info()
             dyn_chunk = max(1, min(_default_batch(N) // 16, -(-len(order) // (8 * world))))
-            if parallel.dist_active() and self.mode == "multi":
+            if local:
+                rec = fit_shard(np.arange(len(order)))
+            elif parallel.dist_active() and self.mode == "multi":
                 rec = parallel.dynamic_map(len(order), fit_stream, dyn_chunk, 5 + width, costs=costs)
                 self.rank_stats = parallel.last_map_stats()
             elif parallel.dist_active():
@@ -620,8 +627,9 @@ class _SearchSession:
                     self.sig_index[sig] = self.prob.add_spec(spec)
                 sc.n_structures += 1
             except _lib.WaveomeAmdError:
-                # beyond the session's capacities: the blocking path, in its own problem
-                callback(sc([(col, kernel)])[0])
+                # beyond the session's capacities: the blocking path, in its own problem - on this rank alone (a
+                # session belongs to one rank; under torch.distributed the other ranks are elsewhere in their searches)
+                callback(sc([(col, kernel)], local=True)[0])
                 return
         sidx = self.sig_index[sig]
         R = sc.num_restart
@@ -787,6 +795,7 @@ def run_searches_sharded(n_columns: int, n_features: int, kern_list: Sequence, s
         merged.update(part)
         totals[0] += int(n_fits or 0)
         totals[1] += int(n_struct or 0)
+    dealer.close()
     parallel._record_stats("dynamic-columns", busy, len(mine))
     scorer.job_totals = {"fits": totals[0], "structures": totals[1]}
     if sorted(merged) != list(range(n_columns)):

@@ -267,16 +267,12 @@ def sharded_map(n_tasks: int, fn: Callable[[np.ndarray], np.ndarray], costs=None
 # ---------------------------------------------------------------------------------------------------------------
 # dynamic dealing: chunks of the task list handed out on demand from a counter every rank can reach
 # ---------------------------------------------------------------------------------------------------------------
-_DEAL_SEQ = [0]
-
-
 class TaskDealer:
     """Hands out the task list in chunks, on demand.  Under torch.distributed the position lives in the process
     group's key-value store (`store.add` is atomic: the TCPStore torchrun already set up, no extra service), so a rank
     that finishes early simply draws the next chunk - what Ray's scheduler did for the reference, one task at a time
     (waveome/model_search.py:474-489, 1200-1222).  The sequence is the same on every rank; without a process group
-    the counter is local.  Every rank must create its dealers in the same sequence (the key is a per-process sequence
-    number).
+    the counter is local.  Creating a dealer is a collective: rank 0 claims the counter's key and broadcasts it.
 
     What a chunk holds: the tasks are sorted by decreasing cost (stable) and chunk j takes every n_chunks-th of them
     (j, j + n_chunks, ...), heaviest first - a CROSS-SECTION of the job.  Contiguous pieces of the sorted list would
@@ -292,28 +288,46 @@ class TaskDealer:
         order = (np.arange(self.n) if costs is None
                  else np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable"))
         n_chunks = max(1, -(-self.n // self.chunk))
-        self.order = np.concatenate([order[j::n_chunks] for j in range(n_chunks)]) if self.n else order
+        # piece j = every n_chunks-th task of the sorted list, starting at j (sizes differ by at most one); a pull hands
+        # out exactly one piece - fixed windows over the concatenation straddled two pieces when n % chunk != 0
+        pieces = [order[j::n_chunks] for j in range(n_chunks)] if self.n else []
+        self.order = np.concatenate(pieces) if pieces else order
+        self._bounds = np.concatenate([[0], np.cumsum([len(q) for q in pieces])]).astype(np.int64)
         world = dist_info()[1] if world is None else int(world)
         self.first_fill = max(self.chunk, int(np.ceil(0.75 * self.n / max(1, world))))
         self.taken = 0          # tasks this rank drew
         self._local = 0
         self._store = None
-        _DEAL_SEQ[0] += 1
-        self._key = f"waveome_amd/deal/{_DEAL_SEQ[0]}"
+        self._key = None
         if dist_active():
             from torch.distributed import distributed_c10d
 
+            # The counter's key has to be the SAME on every rank.  A per-process sequence number is not: a dealer created
+            # on some ranks only (an exception, a retry) would shift it silently and every rank would then deal itself the
+            # whole list.  Rank 0 claims a number from the store and broadcasts it - creating a dealer is a collective
+            # (all callers are), and a rank that creates one alone fails loudly in the broadcast instead.
             self._store = distributed_c10d._get_default_store()
+            box = [int(self._store.add("waveome_amd/deal/next", 1)) if dist_info()[0] == 0 else None]
+            _dist().broadcast_object_list(box, src=0)
+            self._key = f"waveome_amd/deal/{box[0]}"
 
     def pull(self) -> np.ndarray:
-        """The next chunk of task indices (empty once the list is exhausted)."""
+        """The next piece of task indices (empty once the list is exhausted)."""
         if self._store is not None:
-            start = int(self._store.add(self._key, self.chunk)) - self.chunk
+            j = int(self._store.add(self._key, 1)) - 1
         else:
-            start, self._local = self._local, self._local + self.chunk
-        ids = self.order[start:start + self.chunk] if start < self.n else self.order[:0]
+            j, self._local = self._local, self._local + 1
+        ids = self.order[self._bounds[j]:self._bounds[j + 1]] if j + 1 < len(self._bounds) else self.order[:0]
         self.taken += len(ids)
         return ids
+
+    def close(self):
+        """After every rank has stopped pulling (i.e. behind the gather of the map): the counter leaves the store."""
+        if self._store is not None and dist_info()[0] == 0:
+            try:
+                self._store.delete_key(self._key)
+            except Exception:   # (a store without delete_key: the key stays, as before)
+                pass
 
 
 def gather_ragged(local: np.ndarray, local_ids: np.ndarray, n_tasks: int, width: int, device=None) -> np.ndarray:
@@ -394,6 +408,7 @@ def dynamic_map(n_tasks: int, run: Callable[["TaskDealer"], tuple], chunk: int, 
     if len(ids) != dealer.taken:
         raise RuntimeError(f"dynamic_map: run() returned {len(ids)} records for the {dealer.taken} tasks it drew")
     out = gather_ragged(np.asarray(rec, dtype=np.float64).reshape(len(ids), int(width)), ids, n_tasks, width, device)
+    dealer.close()
     _record_stats("dynamic", busy, len(ids), device)
     return out
 

@@ -13,12 +13,29 @@ from . import kernels as K
 _precision = "float64"
 
 
+FLOAT32_LOSS_REL_ERR = 1e-4   # measured: 6.9e-5 at N = 16384, Matern-3/2 (profiles/r03_bench_c5.json); 4e-7 at N = 8192
+
+
 def set_precision(precision: str = "float64"):
-    """Default floating point precision of contexts created afterwards (waveome/utilities.py:34-49):
-    "float32" keeps the N x N work matrices and their MFMA products in float32."""
+    """Default floating point precision of contexts created afterwards (waveome/utilities.py:34-49).
+
+    "float32" is a THROUGHPUT mode, not a parity mode: the N x N work matrices and their MFMA products are float32
+    (the 128-row leaves, the solves and every reduction stay float64), which doubles the matrix rate (C5: 108 TFLOP/s)
+    and carries a relative error of up to ~1e-4 in the loss / LML at N ~ 16384 (95 % of it in log|K_y|: the Schur
+    complements are STORED in float32; refining alpha = K_y^-1 r would not touch it).  The reference's float32
+    (TensorFlow's `set_default_float`) has the same order of error and no statement about it either.  Consequences,
+    stated here because nothing else would tell a user: BIC / log-Bayes-factor differences below ~1e-4 |LML| are noise
+    in this mode; models fitted in different precisions must not be ranked against each other; the north-star tolerance
+    (LML within 1e-6 of the float64 reference) holds in "float64" only.  A warning says so once per process."""
     global _precision
     if precision not in ["float32", "float64"]:
         raise ValueError("Precision must be either 'float32' or 'float64'")
+    if precision == "float32" and _precision != "float32":
+        import warnings
+
+        warnings.warn("waveome_amd: float32 is a throughput mode - losses / LML carry a relative error of up to "
+                      f"~{FLOAT32_LOSS_REL_ERR:g} (float64: 1e-10); do not compare BIC values across precisions",
+                      stacklevel=2)
     _precision = precision
 
 
