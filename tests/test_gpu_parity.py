@@ -429,6 +429,48 @@ def test_fit_trajectory_first_iterations_n2048(ctx):
     prob.close()
 
 
+def test_converged_fits_with_the_reference_options_n512(ctx):
+    """Converged-fit parity: the headline structure at N = 512, three outputs, fitted with the
+    REFERENCE's options - maxiter = maxfun = 50000 and SciPy's default ftol / gtol (waveome/model_classes.py:310-334) -
+    by SciPy L-BFGS-B on the oracle and by the device.  Both end on SciPy's relative-reduction test; each side's
+    objective at the other's end point equals its own to 1e-9 (the same function), and the two end values agree to
+    1e-5 relative.  Not tighter: that test ends a run when ONE iteration gained less than ftol |f| (9e-7 nats here),
+    whatever the gradient, so in these flat valleys both runs stop a few 1e-4 nats short of the optimum at places that
+    depend on the last bits of the path (171 / 186 iterations on column 0) - the assertion after the polish below is
+    the sharp one: continued with that test switched off, both end points reach the same optimum to 1e-8.
+    The same comparison at N = 2048 on six bench columns: tools/converged_fit_parity.py,
+    profiles/r04_converged_fit_parity.txt."""
+    import scipy.optimize
+
+    import bench
+    from waveome_amd.engine import Problem, lbfgs_opts
+
+    X, Y = bench.make_inputs(3)
+    X, Y = X[:512], Y[:, :512]
+    ms = bench.headline_spec()
+    d = ms.to_dict()
+    u0 = ms.unconstrain()
+    prob = Problem(ctx, X, Y.T, ms, max_batch=3)
+    cols = np.arange(3, dtype=np.int32)
+    res = prob.fit(cols, np.tile(u0, (3, 1)), lbfgs_opts(maxiter=50000, maxfun=50000))
+    refs = [scipy.optimize.minimize(lambda u, c=c: o.objective(d, u, X, Y[c]), u0, jac=True, method="L-BFGS-B",
+                                    options=dict(maxiter=50000, maxfun=50000)) for c in range(3)]
+    f_dev_at_ref, _, _ = prob.value_grad(cols, np.stack([r.x for r in refs]))
+    for c in range(3):
+        assert refs[c].success and res["status"][c] in (_lib_codes().LB_CONV_FTOL, _lib_codes().LB_CONV_GTOL), (c, res["status"][c])
+        assert res["loss"][c] == pytest.approx(refs[c].fun, rel=1e-5), (c, res["nit"][c], refs[c].nit)
+        assert f_dev_at_ref[c] == pytest.approx(refs[c].fun, rel=1e-9)
+        f_ora_at_dev, _ = o.objective(d, res["u"][c], X, Y[c])
+        assert f_ora_at_dev == pytest.approx(res["loss"][c], rel=1e-9)
+    tight = lbfgs_opts(maxiter=3000, maxfun=6000, ftol=0.0, gtol=1e-9)
+    pol_d = prob.fit(cols, res["u"], tight)
+    pol_s = prob.fit(cols, np.stack([r.x for r in refs]), tight)
+    for c in range(3):
+        assert pol_d["loss"][c] == pytest.approx(pol_s["loss"][c], rel=1e-8), (c, pol_d["nit"][c], pol_s["nit"][c])
+        assert pol_d["loss"][c] <= res["loss"][c] + 1e-9 and pol_s["loss"][c] <= refs[c].fun + 1e-9
+    prob.close()
+
+
 def test_fit_trajectory_penalised_composite(ctx):
     """The same iteration-by-iteration check on the PENALISED objective of a full_kernel_build-like structure (main
     effects, a categorical, categorical x numeric products with frozen variances, Horseshoe priors on every trainable
