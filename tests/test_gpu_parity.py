@@ -437,7 +437,7 @@ def test_converged_fits_with_the_reference_options_n512(ctx):
     1e-5 relative.  Not tighter: that test ends a run when ONE iteration gained less than ftol |f| (9e-7 nats here),
     whatever the gradient, so in these flat valleys both runs stop a few 1e-4 nats short of the optimum at places that
     depend on the last bits of the path (171 / 186 iterations on column 0) - the assertion after the polish below is
-    the sharp one: continued with that test switched off, both end points reach the same optimum to 1e-8.
+    the sharp one: continued with that test switched off, both end points reach the same optimum to 1e-7 (1e-8 observed).
     The same comparison at N = 2048 on six bench columns: tools/converged_fit_parity.py,
     profiles/r04_converged_fit_parity.txt."""
     import scipy.optimize
@@ -466,7 +466,7 @@ def test_converged_fits_with_the_reference_options_n512(ctx):
     pol_d = prob.fit(cols, res["u"], tight)
     pol_s = prob.fit(cols, np.stack([r.x for r in refs]), tight)
     for c in range(3):
-        assert pol_d["loss"][c] == pytest.approx(pol_s["loss"][c], rel=1e-8), (c, pol_d["nit"][c], pol_s["nit"][c])
+        assert pol_d["loss"][c] == pytest.approx(pol_s["loss"][c], rel=1e-7), (c, pol_d["nit"][c], pol_s["nit"][c])
         assert pol_d["loss"][c] <= res["loss"][c] + 1e-9 and pol_s["loss"][c] <= refs[c].fun + 1e-9
     prob.close()
 
