@@ -413,26 +413,31 @@ def main(out_path):
            "// statements).  The compiler never extracts an element itself: it believes the four values unchanged since",
            "// zero_acc and would be free to read them in front of the loop.  (A \"+a\" hand-back statement behind the loop",
            "// was tried: with it hipcc started copying / spilling the 1024-bit tuples inside the K loop.)",
-           "// Read-out for alpha = +-1 (every product of the pipeline): accumulator (i, j, r) -> the LDS staging image at",
-           "// b<r> + (16 i LDC + 16 j) doubles, sign bit flipped for alpha = -1 (the same bits as the product with -1.0).",
-           "// No float64 multiply - the float64 vector unit is the datapath the partner workgroup's MFMAs are saturating -",
-           "// and no compiler scheduling: hipcc read all 64 accumulators out first and spilled them (round 4).",
-           "__device__ __forceinline__ void stage_acc(const v32i& c0, const v32i& c1, const v32i& c2, const v32i& c3,",
-           "    uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, int sign) {",
-           "  asm volatile(",
-           "      WV_KLOOP_ACC_PRELUDE",
-           "\n".join(
+           "// Read-out for alpha = +-1 (every product of the pipeline): the 32 accumulators of A fragments 2 H, 2 H + 1 (32 rows",
+           "// of the wave's 64 x 64 block) -> the wave's own LDS staging region (row stride 66 doubles) at b<r> + (16 (i & 1) 66",
+           "// + 16 j) doubles, sign bit flipped for alpha = -1 (the same bits as the product with -1.0).  No float64 multiply -",
+           "// the float64 vector unit is the datapath the partner workgroup's MFMAs are saturating - and no compiler scheduling:",
+           "// hipcc read all 64 accumulators out first and spilled them (round 4).",
+           "template <int H> __device__ __forceinline__ void stage_acc_half(const v32i& c0, const v32i& c1, const v32i& c2, const v32i& c3,",
+           "    uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, int sign);"]
+    for H in range(2):
+        out.append(f"template <> __device__ __forceinline__ void stage_acc_half<{H}>(const v32i& c0, const v32i& c1, const v32i& c2, const v32i& c3,")
+        out.append("    uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, int sign) {")
+        out.append("  asm volatile(")
+        out.append("      WV_KLOOP_ACC_PRELUDE")
+        out.append("\n".join(
                f'      "v_accvgpr_read_b32 v{VA0 + 2 * (k % 8)}, a[WVACC{k >> 4}+{2 * (k & 15)}]\\n\\t"\n'
                f'      "v_accvgpr_read_b32 v{VA0 + 2 * (k % 8) + 1}, a[WVACC{k >> 4}+{2 * (k & 15) + 1}]\\n\\t"\n'
                f'      "v_xor_b32 v{VA0 + 2 * (k % 8) + 1}, %[sign], v{VA0 + 2 * (k % 8) + 1}\\n\\t"\n'
-               f'      "ds_write_b64 %[b{k & 3}], v[{VA0 + 2 * (k % 8)}:{VA0 + 2 * (k % 8) + 1}] offset:{((k >> 4) * 16 * 130 + ((k >> 2) & 3) * 16) * 8}\\n\\t"'
-               for k in range(64)),
-           '      "s_waitcnt lgkmcnt(0)\\n\\t"',
-           '      :',
-           '      : [c0] "a"(c0), [c1] "a"(c1), [c2] "a"(c2), [c3] "a"(c3), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3),',
-           '        [sign] "s"(sign)',
-           '      : "memory", ' + ", ".join(f'"v{VA0 + q}"' for q in range(16)) + ');',
-           "}",
+               f'      "ds_write_b64 %[b{k & 3}], v[{VA0 + 2 * (k % 8)}:{VA0 + 2 * (k % 8) + 1}] offset:{(((k >> 4) & 1) * 16 * 66 + ((k >> 2) & 3) * 16) * 8}\\n\\t"'
+               for k in range(32 * H, 32 * H + 32)))
+        out.append('      "s_waitcnt lgkmcnt(0)\\n\\t"')
+        out.append('      :')
+        out.append('      : [c0] "a"(c0), [c1] "a"(c1), [c2] "a"(c2), [c3] "a"(c3), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3),')
+        out.append('        [sign] "s"(sign)')
+        out.append('      : "memory", ' + ", ".join(f'"v{VA0 + q}"' for q in range(16)) + ');')
+        out.append("}")
+    out += [
            "// General alpha (tests only): accumulators 8 G .. 8 G + 7 (A fragment G / 2, doubles 8 (G & 1) ..) as sixteen words",
            "// (low, high) for the caller to scale and stage.",
            "template <int G> __device__ __forceinline__ void read_acc8(const v32i& c0, const v32i& c1, const v32i& c2, const v32i& c3, uint32_t (&w)[16]);"]
