@@ -1795,7 +1795,7 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
     variants = (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
                 ("unpaired", {"WV_PAIR": "0"}),  # (trailing update and T as two launches instead of one)
                 ("wide, one launch per lower-only product", {"WV_BN_FILL": "0", "WV_TRI_SPLIT": "0"}),
-                ("128 x 64 tiles", {"WV_SMALL_FILL": "0"}), ("64-wide leaves", {"WV_LEAF128": "0"}),
+                ("128 x 64 tiles", {"WV_SMALL_FILL": "0"}),
                 ("two batch groups", {"WV_GROUPS": "2"}), ("no block tables", {"WV_BLOCKS": "0"}),
                 ("value through factor + inverse", {"WV_VALUE_FULL": "1"}), ("host trace", {"WV_FIT_TRACE": "1"}))
     for name, extra in variants:

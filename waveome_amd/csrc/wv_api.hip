@@ -25,7 +25,6 @@ static const char* const kTuningSwitches[] = {
     "WV_PAIR",           // 0: trailing update and T as two launches instead of one (few fits in flight)
     "WV_TRI_SPLIT",      // 0: lower-only products as one launch (no diagonal-tile launch)
     "WV_TRI_SPLIT_MIN",  // diagonal tiles a launch needs to get its own diagonal-tile launch (default 256)
-    "WV_LEAF128",        // 0: 64-wide leaves and their products instead of the fused 128-node
     "WV_BLOCKS",         // 0: no zero-block skipping (dense products on block-diagonal structures)
     "WV_VALUE_FULL",     // value-only evaluations through factor + inverse (same LML to rounding, not to the bit)
     "WV_FIT_TRACE",      // host-side timing of a fit loop on stderr (no effect on results)

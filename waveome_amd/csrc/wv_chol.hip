@@ -1005,8 +1005,7 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     launch_potrf_diag(p, st, slot0, nb, (int)o);
     return;
   }
-  static const bool fuse128 = [] { const char* e = tuning_env("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
-  if (n == 2 * NB && fuse128) {  // the whole node in one kernel
+  if (n == 2 * NB) {  // the whole node in one kernel
     launch_potrf128(p, st, slot0, nb, (int)o);
     return;
   }
@@ -1108,8 +1107,7 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
     p.timer.end(st);
     return;
   }
-  static const bool fuse128 = [] { const char* e = tuning_env("WV_LEAF128"); return e ? atoi(e) != 0 : true; }();
-  if (n == 2 * NB && fuse128) {  // fused node: M of the whole 128 block is available, one forward substitution
+  if (n == 2 * NB) {  // fused node: M of the whole 128 block is available, one forward substitution
     launch_potrf128(p, st, slot0, nb, (int)o);
     p.timer.begin(st, ST_SOLVE);
     hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(2 * NB / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o,
