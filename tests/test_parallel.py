@@ -138,9 +138,9 @@ def test_task_dealer_and_dynamic_map_without_a_process_group():
 
     d = parallel.TaskDealer(10, 4, costs=[1, 9, 1, 1, 9, 1, 1, 1, 1, 5], world=2)
     # sorted by decreasing cost (stable): 1 4 9 0 2 3 5 6 7 8; three chunks, chunk j = every third task from j: each a
-    # cross-section of the job with its heaviest task first
+    # cross-section of the job with its heaviest task first; a pull hands out exactly one of them (sizes 4, 3, 3)
     chunks = [d.pull().tolist() for _ in range(4)]
-    assert chunks == [[1, 0, 5, 8], [4, 2, 6, 9], [3, 7], []] and d.taken == 10
+    assert chunks == [[1, 0, 5, 8], [4, 2, 6], [9, 3, 7], []] and d.taken == 10
     assert d.first_fill == 4            # max(chunk, 3/4 of the fair share of 5)
     assert parallel.TaskDealer(3072, 32, world=8).first_fill == 288
     out = parallel.dynamic_map(7, parallel.pull_all(lambda ids: np.column_stack([ids + 0.25, -ids])), chunk=3, width=2)

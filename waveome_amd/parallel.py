@@ -401,6 +401,12 @@ def dynamic_map(n_tasks: int, run: Callable[["TaskDealer"], tuple], chunk: int, 
     import time
 
     dealer = TaskDealer(n_tasks, chunk, costs)
+    if dist_active():
+        # a common start line: the busy times below are compared across ranks, and a rank that leaves the dealer's
+        # broadcast late (100 ms were seen under gloo) would read as imbalance of the dealing
+        import torch
+
+        _dist().all_reduce(torch.zeros(1, dtype=torch.float64, device=collective_device(device)))
     t0 = time.perf_counter()
     ids, rec = run(dealer)
     busy = time.perf_counter() - t0
