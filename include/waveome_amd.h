@@ -273,7 +273,8 @@ typedef struct {
                              gradients are those of the complete cases of that output (what the reference's search
                              does per output, waveome/model_search.py:3034-3043), while all outputs keep sharing one
                              batch.  0 (default): NaN is data and makes every evaluation of that column non-finite.
-                             wv_gram / wv_predict / wv_whitened_means answer WV_E_UNSUPPORTED on such a problem. */
+                             wv_predict and wv_whitened_means work on the complete cases of the column they are asked
+                             about (see there); wv_gram and wv_whitened_state answer WV_E_UNSUPPORTED on such a problem. */
 } wv_problem_caps;
 /* wv_problem_create_multi with explicit capacities (each at least what `specs` need; caps = NULL: exactly that). */
 int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
@@ -302,7 +303,13 @@ void wv_queue_destroy(wv_queue* q);
  * (model_search.py:340, utilities.py:629) via mean_f = y - sigma^2 alpha, var_f = sigma^2 -
  * sigma^4 diag(K_y^-1); otherwise Xnew is a host M x D matrix and mean_out / var_out hold M doubles
  * (var_f = k(x*,x*) - |L^-1 k(X, x*)|^2, full_cov = False).  Either output may be NULL.  This call
- * allocates temporary device memory (it is not on the optimisation loop). */
+ * allocates temporary device memory (it is not on the optimisation loop).
+ * Post-fit calls are float64, complete-case computations whatever the problem: on a float32 problem, or one created
+ * with nan_is_missing, wv_predict / wv_whitened_means (and wv_whitened_state, float32 only) run on a float64
+ * single-column twin that the problem builds from its own device copies on first use and keeps (the workspace of up to
+ * 8 batch slots, freed with the problem; a change of column re-uses it, or rebuilds it when rows are missing).  With
+ * missing outputs the training data of column col are the rows observed for it; Xnew = NULL then still answers all N
+ * rows - a row missing for this column gets the posterior at its input like any new input. */
 int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out);
 
@@ -311,7 +318,7 @@ int32_t wv_predict(wv_problem* prob, int32_t col, const double* theta, const dou
  * (bit t = term t of the spec) while q_mu is kept:  mean_m = chol(K_m + jitter I) q_mu + c,
  * q_mu = chol(K_all + jitter I)' alpha.  This is what `model_copy.kernel.kernels.pop(k)` followed by
  * `predict_y` computes in calc_feature_importance_components (waveome/utilities.py:614-707);
- * jitter = gpflow's default 1e-6.  means_out is n_masks x N. */
+ * jitter = gpflow's default 1e-6.  means_out is n_masks x N (rows missing for this column: NaN). */
 int32_t wv_whitened_means(wv_problem* prob, int32_t col, const double* theta, const uint64_t* term_masks,
                           int32_t n_masks, double jitter, double* means_out);
 
@@ -321,7 +328,8 @@ int32_t wv_whitened_means(wv_problem* prob, int32_t col, const double* theta, co
  *   q_mu   = L' alpha,                         L = chol(K + jitter I),  alpha = K_y^-1 (y - c)
  *   q_sqrt = chol((I + L'L / sigma^2)^-1)      (= chol(I - L' K_y^-1 L))
  * q_mu_out holds N doubles; q_sqrt_out N x N doubles, row-major, lower triangular (strictly upper part zero), or NULL to
- * skip the two extra factorisations it costs.  Same restrictions as wv_whitened_means; not on the optimisation loop. */
+ * skip the two extra factorisations it costs.  Single-structure problems without missing outputs (float32 ones: on their float64 twin); not on the
+ * optimisation loop. */
 int32_t wv_whitened_state(wv_problem* prob, int32_t col, const double* theta, double jitter, double* q_mu_out,
                           double* q_sqrt_out);
 

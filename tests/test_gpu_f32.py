@@ -129,14 +129,38 @@ def test_f32_fit_reaches_the_float64_optimum(ctx32, ctx64):
     np.testing.assert_allclose(th32[:, -1], th64[:, -1], atol=0.1)
 
 
-def test_f32_unsupported_entries_say_so(ctx32):
+def test_post_fit_calls_on_a_float32_problem_are_the_float64_ones(ctx32):
+    """wv_predict / wv_whitened_means / wv_whitened_state are float64 computations whatever the problem's storage type:
+    a float32 problem serves them on a float64 twin it builds from its own device copies (include/waveome_amd.h) -
+    same numbers as the oracle, at float64 tolerances, column after column."""
+    from oracle import gp_oracle as o
     from waveome_amd.engine import Problem
 
     X, Y = _data(3, 100)
-    spec = ModelSpec(K.SquaredExponential(active_dims=[0]), 3, K.GaussianLikelihood(), K.ConstantMean())
-    p = Problem(ctx32, X, Y, spec, max_batch=1)
-    with pytest.raises(Exception, match="float32"):
-        p.predict(0, spec.theta())
+    kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Lin(active_dims=[1])])
+    spec = ModelSpec(kern, 3, K.GaussianLikelihood(), K.ConstantMean())
+    d = spec.to_dict()
+    theta = spec.constrain(spec.unconstrain() + 0.2)
+    rng = np.random.default_rng(8)
+    Xnew = np.column_stack([rng.uniform(-2, 2, 37), rng.normal(size=37), rng.integers(0, 3, 37).astype(float)])
+    p = Problem(ctx32, X, Y, spec, max_batch=2)
+    for col in (1, 0, 1):   # (a change of column re-uses the twin)
+        m, v = p.predict(col, theta)
+        mo, vo = o.predict_train(d, theta, X, Y[:, col])
+        np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(v, vo, rtol=1e-8, atol=1e-10)
+        m, v = p.predict(col, theta, include_noise=False, Xnew=Xnew)
+        mo, vo = o.predict(d, theta, X, Y[:, col], Xnew, include_noise=False)
+        np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(v, vo, rtol=1e-8, atol=1e-10)
+        wm = p.whitened_means(col, theta, [0b01, 0b10, 0b11])
+        wo = o.whitened_means(d, theta, X, Y[:, col], [[0], [1], [0, 1]])
+        np.testing.assert_allclose(wm, wo, rtol=0, atol=2e-6)   # (chol(K + 1e-6 I): the reference's own reproducibility)
+    q_mu, q_sqrt = p.whitened_state(0, theta)
+    assert q_mu.shape == (100,) and np.all(np.isfinite(q_sqrt)) and np.allclose(np.triu(q_sqrt, 1), 0.0)
+    # the float32 fits of the same problem are untouched by the twin
+    f, _, st = p.value_grad(np.array([0], dtype=np.int32), spec.unconstrain()[None, :])
+    assert st[0] == 0 and np.isfinite(f[0])
     p.close()
 
 

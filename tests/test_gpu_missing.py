@@ -58,9 +58,34 @@ def test_value_gradient_and_lml_are_those_of_the_complete_cases(ctx, N):
         assert f[b] == pytest.approx(fo, rel=1e-10, abs=1e-10)
         assert np.max(np.abs(g[b] - go)) <= 1e-7 * max(1.0, np.max(np.abs(go)))
         assert lml[b] == pytest.approx(o.lml(d, thetas[b], X[seen], Y[seen, c]), rel=1e-10, abs=1e-10)
-    # per-row outputs are not defined on such a problem
+    # post-fit calls: those of the complete cases of the column.  Training inputs answer all N rows - a row missing for
+    # the column is predicted like any new input; the component means have no value there (NaN)
+    rng = np.random.default_rng(3)
+    Xnew = np.column_stack([rng.uniform(-2, 2, 29), rng.normal(size=29), rng.integers(0, 4, 29).astype(float)])
+    for c in (1, 0, 3):
+        seen = ~np.isnan(Y[:, c])
+        th = thetas[c]
+        m, v = p.predict(c, th)
+        mo, vo = o.predict_train(d, th, X[seen], Y[seen, c])
+        np.testing.assert_allclose(m[seen], mo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(v[seen], vo, rtol=1e-8, atol=1e-10)
+        if (~seen).any():
+            mo, vo = o.predict(d, th, X[seen], Y[seen, c], X[~seen])
+            np.testing.assert_allclose(m[~seen], mo, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(v[~seen], vo, rtol=1e-8, atol=1e-10)
+        m, v = p.predict(c, th, include_noise=False, Xnew=Xnew)
+        mo, vo = o.predict(d, th, X[seen], Y[seen, c], Xnew, include_noise=False)
+        np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(v, vo, rtol=1e-8, atol=1e-10)
+        wm = p.whitened_means(c, th, [0b0001, 0b1110, 0b1111])
+        wo = o.whitened_means(d, th, X[seen], Y[seen, c], [[0], [1, 2, 3], [0, 1, 2, 3]])
+        np.testing.assert_allclose(wm[:, seen], wo, rtol=0, atol=2e-6)   # (chol(K + 1e-6 I): the reference's own reproducibility)
+        assert np.all(np.isnan(wm[:, ~seen]))
     with pytest.raises(Exception, match="missing outputs"):
-        p.predict(0, thetas[0])
+        p.whitened_state(1, thetas[1])
+    # the fits of the problem are untouched by the twin
+    f3, _, _ = p.value_grad(cols, U)
+    np.testing.assert_array_equal(f3, f)
     p.close()
     # without the flag NaN stays data: every evaluation of such a column is non-finite, the complete column is fine
     q = Problem(ctx, X, Y, spec, max_batch=2)

@@ -319,6 +319,7 @@ int32_t wv_ctx_synchronize(wv_ctx* ctx) {
 void wv_problem_destroy(wv_problem* h) {
   if (!h) return;
   Problem& p = h->p;
+  if (p.twin) wv_problem_destroy(p.twin);
   if (p.ctx) (void)hipSetDevice(p.ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& g : p.groups) {
@@ -375,6 +376,10 @@ int32_t wv_problem_create_multi(wv_ctx* ctx, const double* X, int64_t N, int32_t
   return wv_problem_create_ex(ctx, X, N, D, Y, P, spec_list, n_specs, nullptr, max_batch, x_is_device, y_is_device, out);
 }
 
+static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
+                                 std::vector<Spec> parsed, const wv_problem_caps* caps, int32_t max_batch,
+                                 int32_t x_is_device, int32_t y_is_device, wv_problem** out);
+
 int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
                              const wv_kernel_spec* const* spec_list, int32_t n_specs, const wv_problem_caps* caps,
                              int32_t max_batch, int32_t x_is_device, int32_t y_is_device, wv_problem** out) {
@@ -386,27 +391,39 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
     set_error("N too large");
     return WV_E_BADARG;
   }
-  std::unique_ptr<wv_problem, void (*)(wv_problem*)> h(new wv_problem(), wv_problem_destroy);
-  Problem& p = h->p;
-  p.ctx = &ctx->c;
-  p.f32 = ctx->c.dtype == 1;
-  p.specs.resize(n_specs);
-  std::vector<DevSpec> hspecs(n_specs);
+  std::vector<Spec> parsed(n_specs);
   for (int si = 0; si < n_specs; ++si) {
     if (!spec_list[si]) {
       set_error("wv_problem_create: null spec");
       return WV_E_BADARG;
     }
-    std::string e = Spec::parse(spec_list[si], p.specs[si]);
+    std::string e = Spec::parse(spec_list[si], parsed[si]);
     if (!e.empty()) {
       set_error(e);
       return WV_E_SPEC;
     }
-    if (p.specs[si].n_dims != D) {
+    if (parsed[si].n_dims != D) {
       set_error("spec.n_dims != D");
       return WV_E_SPEC;
     }
-    e = build_devspec(p.specs[si], hspecs[si]);
+  }
+  return create_from_specs(&ctx->c, X, N, D, Y, P, std::move(parsed), caps, max_batch, x_is_device, y_is_device, out);
+}
+
+// The problem proper, from parsed structures (the float64 twin of a float32 / missing-output problem is made here from
+// the parent's own tables and device copies: post_fit_twin).
+static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D, const double* Y, int32_t P,
+                                 std::vector<Spec> parsed, const wv_problem_caps* caps, int32_t max_batch,
+                                 int32_t x_is_device, int32_t y_is_device, wv_problem** out) {
+  const int n_specs = (int)parsed.size();
+  std::unique_ptr<wv_problem, void (*)(wv_problem*)> h(new wv_problem(), wv_problem_destroy);
+  Problem& p = h->p;
+  p.ctx = ctx;
+  p.f32 = ctx->dtype == 1;
+  p.specs = std::move(parsed);
+  std::vector<DevSpec> hspecs(n_specs);
+  for (int si = 0; si < n_specs; ++si) {
+    std::string e = build_devspec(p.specs[si], hspecs[si]);
     if (!e.empty()) {
       set_error(e);
       return WV_E_UNSUPPORTED;
@@ -435,7 +452,7 @@ int32_t wv_problem_create_ex(wv_ctx* ctx, const double* X, int64_t N, int32_t D,
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
   p.spec = p.specs[0];
   p.hspec = hspecs[0];
-  WV_HIP_TRY(hipSetDevice(ctx->c.device));
+  WV_HIP_TRY(hipSetDevice(ctx->device));
   p.N = N;
   p.Npad = (N + NB - 1) / NB * NB;
   p.D = D;
@@ -1091,6 +1108,65 @@ static double kernel_diag_at(const Spec& s, const double* theta, const double* x
   return tot;
 }
 
+// The float64, complete-case twin that serves the post-fit calls of a float32 problem or of one with missing outputs
+// (Problem::twin).  One column at a time: without missing values a change of column is one device copy of Y's column;
+// with them the observed rows differ from column to column and the twin is rebuilt (7 ms at N = 2048; these calls are
+// one evaluation each, after the fits).
+static int32_t post_fit_twin(Problem& p, int col, const char* who) {
+  if (p.specs.size() != 1) {
+    set_error(std::string(who) + ": the problem holds several structures (only wv_fit_multi serves those)");
+    return WV_E_UNSUPPORTED;
+  }
+  if (p.open_queue) {
+    set_error(std::string(who) + ": a wv_queue is open on this problem");
+    return WV_E_BADARG;
+  }
+  WV_HIP_TRY(hipSetDevice(p.ctx->device));
+  if (p.twin && p.twin_col == col) return WV_OK;
+  if (p.twin && !p.dmask) {
+    WV_HIP_TRY(hipMemcpy(p.twin->p.dY, p.dY + (int64_t)col * p.Npad, sizeof(double) * p.Npad, hipMemcpyDeviceToDevice));
+    p.twin_col = col;
+    return WV_OK;
+  }
+  if (p.twin) {
+    wv_problem_destroy(p.twin);
+    p.twin = nullptr;
+    p.twin_col = -1;
+  }
+  p.ctx64 = *p.ctx;
+  p.ctx64.dtype = 0;
+  // batch slots: wv_whitened_means factors its leave-one-out Gram matrices as a batch - up to 8, within 8 GiB
+  const int64_t per_slot = 4 * (int64_t)sizeof(double) * p.Npad * p.Npad;
+  const int slots = (int)std::max<int64_t>(1, std::min<int64_t>(8, ((int64_t)8 << 30) / per_slot));
+  int32_t rc;
+  p.twin_rows.clear();
+  if (!p.dmask) {
+    rc = create_from_specs(&p.ctx64, p.dX, p.N, p.D, p.dY + (int64_t)col * p.Npad, 1, {p.spec}, nullptr, slots, 1, 1, &p.twin);
+  } else {
+    std::vector<uint8_t> mask(p.N);
+    std::vector<double> X((size_t)p.N * p.D), y(p.N);
+    WV_HIP_TRY(hipMemcpy(mask.data(), p.dmask + (int64_t)col * p.Npad, p.N, hipMemcpyDeviceToHost));
+    WV_HIP_TRY(hipMemcpy(X.data(), p.dX, sizeof(double) * p.N * p.D, hipMemcpyDeviceToHost));
+    WV_HIP_TRY(hipMemcpy(y.data(), p.dY + (int64_t)col * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (int64_t i = 0; i < p.N; ++i)
+      if (mask[i]) {
+        if (n != i) std::copy(X.begin() + i * p.D, X.begin() + (i + 1) * p.D, X.begin() + n * p.D);
+        y[n++] = y[i];
+        p.twin_rows.push_back(i);
+      }
+    if (n == p.N) p.twin_rows.clear();  // (this column is complete)
+    rc = create_from_specs(&p.ctx64, X.data(), n, p.D, y.data(), 1, {p.spec}, nullptr, slots, 0, 0, &p.twin);
+  }
+  if (rc != WV_OK) {
+    p.twin = nullptr;
+    p.twin_rows.clear();
+    return rc;
+  }
+  p.twin_col = col;
+  return WV_OK;
+}
+
 int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double* Xnew, int64_t M,
                    int32_t include_noise, double* mean_out, double* var_out) {
   if (!h || !theta || col < 0 || col >= h->p.P || (Xnew && M < 1)) {
@@ -1098,16 +1174,41 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
     return WV_E_BADARG;
   }
   Problem& p = h->p;
-  if (p.dmask) {
-    set_error("wv_predict: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
-    return WV_E_UNSUPPORTED;
+  if (p.f32 || p.dmask) {
+    // float64 on the complete cases of this column (Problem::twin).  Training inputs of a problem with missing outputs:
+    // all N rows - the observed ones by the training-input identities, the others as new inputs.
+    if (int rc = post_fit_twin(p, col, "wv_predict")) return rc;
+    if (Xnew || p.twin_rows.empty()) return wv_predict(p.twin, 0, theta, Xnew, M, include_noise, mean_out, var_out);
+    const int64_t n = (int64_t)p.twin_rows.size(), nmiss = p.N - n;
+    std::vector<double> m(std::max(n, nmiss)), v(std::max(n, nmiss));
+    if (int rc = wv_predict(p.twin, 0, theta, nullptr, 0, include_noise, mean_out ? m.data() : nullptr, var_out ? v.data() : nullptr))
+      return rc;
+    std::vector<uint8_t> seen(p.N, 0);
+    for (int64_t k = 0; k < n; ++k) {
+      const int64_t i = p.twin_rows[k];
+      seen[i] = 1;
+      if (mean_out) mean_out[i] = m[k];
+      if (var_out) var_out[i] = v[k];
+    }
+    std::vector<double> Xall((size_t)p.N * p.D), Xm((size_t)nmiss * p.D);
+    WV_HIP_TRY(hipMemcpy(Xall.data(), p.dX, sizeof(double) * p.N * p.D, hipMemcpyDeviceToHost));
+    std::vector<int64_t> miss;
+    for (int64_t i = 0; i < p.N; ++i)
+      if (!seen[i]) {
+        std::copy(Xall.begin() + i * p.D, Xall.begin() + (i + 1) * p.D, Xm.begin() + (int64_t)miss.size() * p.D);
+        miss.push_back(i);
+      }
+    if (int rc = wv_predict(p.twin, 0, theta, Xm.data(), nmiss, include_noise, mean_out ? m.data() : nullptr,
+                            var_out ? v.data() : nullptr))
+      return rc;
+    for (int64_t k = 0; k < nmiss; ++k) {
+      if (mean_out) mean_out[miss[k]] = m[k];
+      if (var_out) var_out[miss[k]] = v[k];
+    }
+    return WV_OK;
   }
   if (p.specs.size() != 1) {
     set_error("wv_predict: the problem holds several structures (only wv_fit_multi serves those)");
-    return WV_E_UNSUPPORTED;
-  }
-  if (p.f32) {
-    set_error("wv_predict: not implemented for float32 problems (create the problem on a float64 context)");
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
@@ -1212,16 +1313,20 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
     return WV_E_BADARG;
   }
   Problem& p = h->p;
-  if (p.dmask) {
-    set_error("wv_whitened_means: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
-    return WV_E_UNSUPPORTED;
+  if (p.f32 || p.dmask) {
+    // float64 on the complete cases of this column (Problem::twin); rows missing for this column answer NaN
+    if (int rc = post_fit_twin(p, col, "wv_whitened_means")) return rc;
+    if (p.twin_rows.empty()) return wv_whitened_means(p.twin, 0, theta, term_masks, n_masks, jitter, means_out);
+    const int64_t n = (int64_t)p.twin_rows.size();
+    std::vector<double> mm((size_t)n_masks * n);
+    if (int rc = wv_whitened_means(p.twin, 0, theta, term_masks, n_masks, jitter, mm.data())) return rc;
+    std::fill(means_out, means_out + (int64_t)n_masks * p.N, std::numeric_limits<double>::quiet_NaN());
+    for (int m = 0; m < n_masks; ++m)
+      for (int64_t k = 0; k < n; ++k) means_out[(int64_t)m * p.N + p.twin_rows[k]] = mm[(size_t)m * n + k];
+    return WV_OK;
   }
   if (p.specs.size() != 1) {
     set_error("wv_whitened_means: the problem holds several structures (only wv_fit_multi serves those)");
-    return WV_E_UNSUPPORTED;
-  }
-  if (p.f32) {
-    set_error("wv_whitened_means: not implemented for float32 problems (create the problem on a float64 context)");
     return WV_E_UNSUPPORTED;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
@@ -1303,16 +1408,16 @@ int32_t wv_whitened_state(wv_problem* h, int32_t col, const double* theta, doubl
   }
   Problem& p = h->p;
   if (p.dmask) {
-    set_error("wv_whitened_state: the problem has missing outputs (nan_is_missing): fits, LML and gradients only");
+    set_error("wv_whitened_state: the problem has missing outputs (nan_is_missing): the variational state of a column lives on its observed rows only - build a problem on those rows");
     return WV_E_UNSUPPORTED;
   }
   if (p.specs.size() != 1) {
     set_error("wv_whitened_state: the problem holds several structures (only wv_fit_multi serves those)");
     return WV_E_UNSUPPORTED;
   }
-  if (p.f32) {
-    set_error("wv_whitened_state: not implemented for float32 problems (create the problem on a float64 context)");
-    return WV_E_UNSUPPORTED;
+  if (p.f32) {  // float64 on a twin of this problem (Problem::twin)
+    if (int rc = post_fit_twin(p, col, "wv_whitened_state")) return rc;
+    return wv_whitened_state(p.twin, 0, theta, jitter, q_mu_out, q_sqrt_out);
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
   int rc = enter_device_call(p, "wv_whitened_state");

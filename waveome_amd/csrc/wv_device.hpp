@@ -24,6 +24,8 @@
 
 #include "wv_spec.hpp"
 
+struct wv_problem;  // (the C-ABI handle: wv_api.hip)
+
 namespace wv {
 
 constexpr int NB = 64;          // diagonal block / panel width
@@ -202,6 +204,14 @@ struct Problem {
   std::vector<Group> groups;
   StageTimer timer;
   bool open_queue = false;  // a wv_queue owns the groups' staging buffers: every other device entry point is refused
+  // Post-fit calls (wv_predict, wv_whitened_means, wv_whitened_state) are float64, complete-case computations.  A float32
+  // problem, or one with missing outputs, serves them on a float64 single-column twin of itself, made on first use from
+  // its own device copies (wv_api.hip, post_fit_twin): column twin_col of Y, and - with missing outputs - only the rows
+  // observed for that column (twin_rows: their indices in this problem; empty = all rows).
+  Ctx ctx64;
+  ::wv_problem* twin = nullptr;
+  int twin_col = -1;
+  std::vector<int64_t> twin_rows;
   int64_t pbuf_elems() const { int64_t h = Npad / 2 + NB; return std::max<int64_t>(h * h, Npad * NB); }
   int nblk() const { return (int)(Npad / NB); }
   int ntiles() const { int t = (int)(Npad / GT); return t * (t + 1) / 2; }

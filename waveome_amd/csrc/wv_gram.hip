@@ -206,6 +206,144 @@ __device__ inline void stage_exp_table(double* tab, int tid) {
   for (int q = tid; q < EXPTAB_DOUBLES; q += 256) tab[q] = kExp2Tab[q >> 5];
 }
 
+#ifdef WV_EXPERIMENTS
+// ---- exp2_64 variants side by side (tools/probe_exp_rate.py): rate of each and bit identity against variant 0 ----
+//  1: the five Horner steps as 3-address v_fma_f64 with the coefficients in SGPRs (hipcc emits v_fmac + a 64-bit move
+//     of the coefficient per step: 862 v_mov_b64 beside 2320 fp64 arithmetic instructions in the Gram kernel)
+//  2: + rint / convert by the 1.5 * 2^52 shift (two adds; the integer is the low word of the shifted sum)
+//  3: + the power of two added into the exponent field instead of v_ldexp_f64
+template <int V>
+__device__ inline double exp2_64_variant(double t, const double* __restrict__ tab) {
+  if (V == 0) return exp2_64(t, tab);
+  double kd, r;
+  int k;
+  if (V >= 2) {
+    const double big = 6755399441055744.0;  // 1.5 * 2^52
+    const double sh = t + big;
+    kd = sh - big;
+    k = __double2loint(sh);
+  } else {
+    kd = rint(t);
+    k = (int)kd;
+  }
+  r = t - kd;
+  double p;
+  const double c5 = 1.2417843701716925e-12, c4 = 5.732851688640402e-10, c3 = 2.1173137155464776e-07,
+               c2 = 5.86490495505617e-05, c1 = 0.010830424696249145;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c5), "v"(r), "v"(c4));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"(c3));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"(c2));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"(c1));
+  p = fma(p, r, 1.0);
+  typedef const __attribute__((address_space(3))) double* lds_cdp;
+  const uint32_t lane_addr = (uint32_t)(size_t)(lds_cdp)tab;
+  const uint32_t addr = (((uint32_t)k << 8) & 0x3f00u) | lane_addr;
+  const double v = *(lds_cdp)(size_t)addr * p;
+  if (V >= 3) {
+    const int hi = __double2hiint(v) + ((k >> 6) << 20);
+    return __hiloint2double(hi, __double2loint(v));
+  }
+  return ldexp(v, k >> 6);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void exp_rate_kernel(double* __restrict__ out, int iters, double t0, double dt) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  stage_exp_table(smem, threadIdx.x);
+  __syncthreads();
+  const double* tab = smem + (threadIdx.x & 31);
+  double t[8], acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    t[q] = t0 - 1e-3 * (double)(threadIdx.x + 256 * (blockIdx.x & 63)) - 7.3 * q;
+    acc[q] = 0.0;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[q] += exp2_64_variant<V>(t[q], tab);
+      t[q] -= dt;
+    }
+  }
+  double a = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a += acc[q];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = a;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void exp_check_kernel(const double* __restrict__ t, int64_t n, unsigned long long* __restrict__ bad,
+                                                        double* __restrict__ first_bad) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  stage_exp_table(smem, threadIdx.x);
+  __syncthreads();
+  const double* tab = smem + (threadIdx.x & 31);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double a = exp2_64(t[i], tab), b = exp2_64_variant<V>(t[i], tab);
+    if (__double_as_longlong(a) != __double_as_longlong(b))
+      if (atomicAdd(bad, 1ull) == 0) { first_bad[0] = t[i]; first_bad[1] = a; first_bad[2] = b; }
+  }
+}
+
+}  // namespace wv
+extern "C" int32_t wv_dbg_exp_rate(int32_t variant, int32_t iters, int32_t waves_per_simd, double t0, double dt,
+                                   double* gexp_per_s_out) {
+  using namespace wv;
+  hipDeviceProp_t prop;
+  WV_HIP_TRY(hipGetDeviceProperties(&prop, 0));
+  const int blocks = prop.multiProcessorCount * waves_per_simd;
+  double* d;
+  WV_HIP_TRY(hipMalloc(&d, sizeof(double) * blocks * 256));
+  hipEvent_t a, b;
+  WV_HIP_TRY(hipEventCreate(&a));
+  WV_HIP_TRY(hipEventCreate(&b));
+  const size_t sh = sizeof(double) * EXPTAB_DOUBLES;
+  auto go = [&](int n) {
+    switch (variant) {
+      case 0: hipLaunchKernelGGL(exp_rate_kernel<0>, dim3(blocks), dim3(256), sh, nullptr, d, n, t0, dt); break;
+      case 1: hipLaunchKernelGGL(exp_rate_kernel<1>, dim3(blocks), dim3(256), sh, nullptr, d, n, t0, dt); break;
+      case 2: hipLaunchKernelGGL(exp_rate_kernel<2>, dim3(blocks), dim3(256), sh, nullptr, d, n, t0, dt); break;
+      default: hipLaunchKernelGGL(exp_rate_kernel<3>, dim3(blocks), dim3(256), sh, nullptr, d, n, t0, dt); break;
+    }
+  };
+  go(iters / 8 + 1);
+  WV_HIP_TRY(hipEventRecord(a, nullptr));
+  go(iters);
+  WV_HIP_TRY(hipEventRecord(b, nullptr));
+  WV_HIP_TRY(hipEventSynchronize(b));
+  float ms = 0;
+  WV_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  if (gexp_per_s_out) *gexp_per_s_out = (double)blocks * 256.0 * 8.0 * iters / (ms * 1e-3) / 1e9;
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(d);
+  return WV_OK;
+}
+extern "C" int32_t wv_dbg_exp_check(int32_t variant, const double* t_host, int64_t n, int64_t* n_bad_out, double* first_bad3_out) {
+  using namespace wv;
+  double *dt_, *fb;
+  unsigned long long* bad;
+  WV_HIP_TRY(hipMalloc(&dt_, sizeof(double) * n));
+  WV_HIP_TRY(hipMalloc(&fb, sizeof(double) * 3));
+  WV_HIP_TRY(hipMalloc(&bad, sizeof(unsigned long long)));
+  WV_HIP_TRY(hipMemcpy(dt_, t_host, sizeof(double) * n, hipMemcpyHostToDevice));
+  WV_HIP_TRY(hipMemset(bad, 0, sizeof(unsigned long long)));
+  WV_HIP_TRY(hipMemset(fb, 0, sizeof(double) * 3));
+  const size_t sh = sizeof(double) * EXPTAB_DOUBLES;
+  switch (variant) {
+    case 1: hipLaunchKernelGGL(exp_check_kernel<1>, dim3(1024), dim3(256), sh, nullptr, dt_, n, bad, fb); break;
+    case 2: hipLaunchKernelGGL(exp_check_kernel<2>, dim3(1024), dim3(256), sh, nullptr, dt_, n, bad, fb); break;
+    default: hipLaunchKernelGGL(exp_check_kernel<3>, dim3(1024), dim3(256), sh, nullptr, dt_, n, bad, fb); break;
+  }
+  WV_HIP_TRY(hipDeviceSynchronize());
+  unsigned long long nb = 0;
+  WV_HIP_TRY(hipMemcpy(&nb, bad, sizeof(nb), hipMemcpyDeviceToHost));
+  if (first_bad3_out) WV_HIP_TRY(hipMemcpy(first_bad3_out, fb, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  if (n_bad_out) *n_bad_out = (int64_t)nb;
+  hipFree(dt_); hipFree(fb); hipFree(bad);
+  return WV_OK;
+}
+namespace wv {
+#endif  // WV_EXPERIMENTS
+
 // One factor on the thread's 4 x 4 elements.
 //   MODE 0: k[a][c]  = factor value                        (a factor of a product)
 //   MODE 1: k[a][c] += factor value                        (a single-factor term, accumulated into the sum)

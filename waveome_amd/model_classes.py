@@ -45,19 +45,6 @@ def default_context(device: Optional[int] = None) -> Context:
     return _default_ctx
 
 
-_ctx64 = {}
-
-
-def float64_context(ctx: Context) -> Context:
-    """Posterior prediction and the component means are float64-only in the C-ABI: on a float32 context they run
-    on a float64 context of the same device (fitting is where float32 pays; these are one evaluation each)."""
-    if ctx.dtype == "float64":
-        return ctx
-    if ctx.device not in _ctx64:
-        _ctx64[ctx.device] = Context(ctx.device, dtype="float64")
-    return _ctx64[ctx.device]
-
-
 class ProblemPool:
     """Device problems on one (X, Y) keyed by kernel structure; `Y` holds every output column."""
 
@@ -153,14 +140,13 @@ class PSVGP:
                     p.prior = prior
 
     # ---- GPU-backed numerics ----------------------------------------------------------
-    def _problem(self, max_batch=2, f64=False):
+    def _problem(self, max_batch=2):
         """(spec, problem) for this model's data and current structure.  Models built by GPSearch share a
         ProblemPool: outputs whose (pruned) kernels have the same structure reuse one device problem that holds
         every output column, instead of allocating one each (7 + 2 ms per model, as much as a small fit).
-        f64: the call needs a float64 problem (prediction, component means)."""
+        Prediction and the component means are float64 computations on any problem (a float32 one serves them on a
+        float64 twin inside the library: include/waveome_amd.h, wv_predict)."""
         ctx = self._ctx or default_context()
-        if f64:
-            ctx = float64_context(ctx)
         spec = self._spec()
         if self._pool is not None:
             return spec, self._pool.get(spec)
@@ -245,7 +231,7 @@ class PSVGP:
         return _Inducing(self.data[0])
 
     def _whitened_state(self, want_sqrt):
-        spec, prob = self._problem(f64=True)
+        spec, prob = self._problem()
         try:
             return prob.whitened_state(self._col, spec.theta(), want_sqrt=want_sqrt)
         finally:
@@ -277,7 +263,7 @@ class PSVGP:
         """Posterior mean / variance of f (model_classes.py:526-534); full_cov is not supported."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full_cov=True is not implemented")
-        spec, prob = self._problem(f64=True)
+        spec, prob = self._problem()
         mean, var = prob.predict(self._col, spec.theta(), include_noise=False, Xnew=self._xnew(Xnew))
         self._release(prob)
         return mean[:, None], var[:, None]
@@ -286,7 +272,7 @@ class PSVGP:
         """Posterior mean / variance of y (model_classes.py:536-544)."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full_cov=True is not implemented")
-        spec, prob = self._problem(f64=True)
+        spec, prob = self._problem()
         mean, var = prob.predict(self._col, spec.theta(), include_noise=True, Xnew=self._xnew(Xnew))
         self._release(prob)
         return mean[:, None], var[:, None]
@@ -434,7 +420,7 @@ class PSVGP:
         [full, component 0 alone, 1 alone, ...] as individual_kernel_predictions does for calc_rsquare
         (utilities.py:162-172, 770-780)."""
         self._own_data_only(data, "component_means")
-        spec, prob = self._problem(f64=True)
+        spec, prob = self._problem()
         comps = self.kernel.kernels if self.kernel.name == "sum" else [self.kernel]
         # additive component k owns a contiguous run of flattened terms (products of sums expand)
         counts = [len(_expand(k)) for k in comps]

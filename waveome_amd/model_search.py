@@ -18,7 +18,7 @@ import pandas as pd
 from . import kernels as K
 from . import parallel
 from .engine import Problem, lbfgs_opts
-from .model_classes import PSVGP, ProblemPool, default_context, float64_context
+from .model_classes import PSVGP, ProblemPool, default_context
 from .regularization import full_kernel_build
 from .spec import ModelSpec
 
@@ -224,16 +224,13 @@ class GPSearch:
                                                                    (1.0 / pf[cols[t]]) if has_prior else None),
                                            opts, first_fill=dealer.first_fill)
             u, pf_used = res["u"], pf[cols[ids]].copy()
-            # predict_y of the factor iteration is float64-only: a float32 run predicts on a float64 twin
-            pprob = prob if ctx.dtype == "float64" or not iterating else Problem(float64_context(ctx), Xn, Yn, spec,
-                                                                                  max_batch=1)
             extra = np.zeros((len(ids), 2))  # total iterations / evaluations over the factor re-fits
             if iterating:
                 live = np.arange(len(ids))
                 for _ in range(int(num_factor_iter)):
                     keep = []
                     for k in live:
-                        _, var = pprob.predict(int(cols[ids][k]), spec.constrain(u[k]), include_noise=True)
+                        _, var = prob.predict(int(cols[ids][k]), spec.constrain(u[k]), include_noise=True)
                         new_pf = 2 * 1.1 * np.sqrt(np.mean(var)) * np.sqrt(Xn.shape[0]) * zq
                         if verbose:
                             print("New penalization factor:" f" {new_pf}")
@@ -250,8 +247,6 @@ class GPSearch:
                         res[key][live] = r2[key]
                     extra[live, 0] += r2["nit"]
                     extra[live, 1] += r2["nfev"]
-            if pprob is not prob:
-                pprob.close()
             prob.close()
             rec = np.column_stack([res["loss"], res["lml"], res["nit"] + extra[:, 0], res["nfev"] + extra[:, 1],
                                    res["status"], pf_used, u])
@@ -271,7 +266,7 @@ class GPSearch:
             rec = fit_shard(np.arange(len(cols)))
         self.fit_records = rec
         self.models = {}
-        pool = ProblemPool(float64_context(ctx), Xn, Yn)  # post-fit steps of outputs with the same pruned structure share a problem
+        pool = ProblemPool(ctx, Xn, Yn)  # post-fit steps of outputs with the same pruned structure share a problem
         for p, feat in enumerate(self.out_names):
             block = rec[p * n_starts:(p + 1) * n_starts]
             # restarts: keep the highest maximum_log_likelihood_objective (model_classes.py:511-519)
