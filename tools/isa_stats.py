@@ -14,11 +14,10 @@ def main():
         blk = ".agpr_count:" + blk
         get = lambda k: (re.search(r"\.%s:\s*(\S+)" % k, blk) or [None, "?"])[1]
         name = get("name")
-        try:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
-        except Exception:
-            pass
-        name = re.sub(r"\(.*", "", name)
+        m = re.match(r"_ZN2wv\d+([a-z0-9_]+?)(I[A-Za-z0-9_]*?)?EE?vP", name)   # wv::name<template args>(...)
+        if m:
+            args = re.findall(r"Lb([01])E|Li(\d+)E|^I([fd])|(?<=I)([fd])", m.group(2) or "")
+            name = m.group(1) + ("<" + ",".join(next(x for x in a if x) for a in args) + ">" if args else "")
         if flt in name:
             rows.append((name, get("vgpr_count"), get("agpr_count"), get("sgpr_count"), get("private_segment_fixed_size"),
                          get("vgpr_spill_count"), get("group_segment_fixed_size"), get("max_flat_workgroup_size")))

@@ -26,6 +26,8 @@
 // columns 4 tx .. 4 tx + 3 (32-byte row segments -> 512 B contiguous per 16 threads).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "wv_device.hpp"
 
 namespace wv {
@@ -125,6 +127,11 @@ __device__ inline void factor_constants(const DevFactor& f, const double* __rest
 // `tab` = this lane's slice of the table (table base + (lane & 31) doubles).  The table is the first 16 KB of the
 // workgroup's LDS (offset 0: the kernels here have no static __shared__ data - launch_* check it once), so the entry's
 // address is (j << 8) OR-ed into the lane's: one v_and_or_b32 instead of and + add.
+// (Forms that were measured against this one and not kept - microbenchmark tools/probe_exp_rate.py and the kernels
+//  themselves, profiles/r04_exp_rate.txt, profiles/r04_gram_trace_ab.txt: rint / convert by the 1.5 * 2^52 shift, the Horner
+//  steps as 3-address v_fma_f64 with SGPR coefficients, four chains of a row phase by phase between scheduling barriers.
+//  Bit-identical all of them, 14 % faster in the microbenchmark, and within +-1 % - or slower, with the range clamp the
+//  shift needs - inside the Gram and trace kernels.)
 __device__ inline double exp2_64(double t, const double* __restrict__ tab) {
   const double kd = rint(t);
   const double r = t - kd;
@@ -208,8 +215,8 @@ __device__ inline void stage_exp_table(double* tab, int tid) {
 
 #ifdef WV_EXPERIMENTS
 // ---- exp2_64 variants side by side (tools/probe_exp_rate.py): rate of each and bit identity against variant 0 ----
-//  1: the five Horner steps as 3-address v_fma_f64 with the coefficients in SGPRs (hipcc emits v_fmac + a 64-bit move
-//     of the coefficient per step: 862 v_mov_b64 beside 2320 fp64 arithmetic instructions in the Gram kernel)
+//  1: the five Horner steps as 3-address v_fma_f64 with the coefficients in SGPRs (inside the Gram kernel hipcc emits
+//     v_fmac + a 64-bit move of the coefficient per step: 862 v_mov_b64 beside 2320 fp64 arithmetic instructions)
 //  2: + rint / convert by the 1.5 * 2^52 shift (two adds; the integer is the low word of the shifted sum)
 //  3: + the power of two added into the exponent field instead of v_ldexp_f64
 template <int V>
@@ -355,7 +362,7 @@ namespace wv {
 #define WV_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <int MODE, bool MULTI = true>
-__device__ inline void factor_tile(const DevFactor& f, const double* __restrict__ fc,
+__device__ __forceinline__ void factor_tile(const DevFactor& f, const double* __restrict__ fc,
                                    const int16_t* __restrict__ slots, const TileCtx& t, double (&k)[4][4],
                                    const double (&wo)[4][4], double (&s)[3]) {
   const int type = f.type;
@@ -367,76 +374,107 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
     else if (MODE == 3) k[a][c] *= scale * v;
   };
   if (type == WV_K_SE || type == WV_K_M12 || type == WV_K_M32 || type == WV_K_M52) {
-    // per-element work given the squared distance q on the factor's columns
-    auto elem = [&](int a, int c, double q) {
-      if (type == WV_K_SE) {
-        const double tt = q * c0, e = exp2_64(tt, t.tab);
-        if (MODE == 2) { const double we = wo[a][c] * e; s0 += we; s1 = fma(we, tt, s1); }
-        else emit(a, c, var, e);
-      } else {
-        const double u = sqrt(q) * c0, e = exp2_64(-u, t.tab), z = u * kLn2_64;
-        double gg, dl;  // k = var gg, dk/dl = var dl / l
-        if (type == WV_K_M12) { gg = e; dl = z * e; }
-        else if (type == WV_K_M32) { gg = (1.0 + z) * e; dl = z * z * e; }
-        else { const double z23 = z * z * (1.0 / 3.0); gg = (1.0 + z + z23) * e; dl = z23 * (1.0 + z) * e; }
-        if (MODE == 2) { s0 = fma(wo[a][c], gg, s0); s1 = fma(wo[a][c], dl, s1); }
-        else emit(a, c, var, gg);
-      }
-    };
-    if (!MULTI || f.ndims == 1) {
-      const int sl = slots[f.slot0];
-      double xj[4];
+    // The kernel type is a compile-time tag of the row loops (one copy of them per stationary type): with the type tested
+    // per element hipcc kept the tests (scalar branches) inside the loops.  Measured at 512 fits, N = 2048, same box
+    // (profiles/r04_gram_trace_ab.txt): trace pass 6.34 -> 5.78 ms, Gram pass 5.39 -> 5.29 (4 waves) / 5.14 ms (3 waves).
+    auto rows = [&](auto tag) __attribute__((always_inline)) {
+      constexpr int TY = decltype(tag)::value;
+      // a row of four elements given their squared distances q on the factor's columns
+      auto row = [&](int a, const double (&q)[4]) __attribute__((always_inline)) {
+        double tt[4], e[4];
+        if constexpr (TY == WV_K_SE) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xj[c] = t.fj[sl * GT + 4 * t.tx + c];
+          for (int c = 0; c < 4; ++c) tt[c] = q[c] * c0;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const double xi = t.fi[sl * GT + t.ty + 16 * a];
+          for (int c = 0; c < 4; ++c) e[c] = exp2_64(tt[c], t.tab);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double df = xi - xj[c];  // differences first: no cancellation for short lengthscales
-          elem(a, c, df * df);
+          for (int c = 0; c < 4; ++c) {
+            if (MODE == 2) { const double we = wo[a][c] * e[c]; s0 += we; s1 = fma(we, tt[c], s1); }
+            else emit(a, c, var, e[c]);
+          }
+        } else {
+          double u[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { u[c] = sqrt(q[c]) * c0; tt[c] = -u[c]; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) e[c] = exp2_64(tt[c], t.tab);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double z = u[c] * kLn2_64;
+            double gg, dl;  // k = var gg, dk/dl = var dl / l
+            if constexpr (TY == WV_K_M12) { gg = e[c]; dl = z * e[c]; }
+            else if constexpr (TY == WV_K_M32) { gg = (1.0 + z) * e[c]; dl = z * z * e[c]; }
+            else { const double z23 = z * z * (1.0 / 3.0); gg = (1.0 + z + z23) * e[c]; dl = z23 * (1.0 + z) * e[c]; }
+            if (MODE == 2) { s0 = fma(wo[a][c], gg, s0); s1 = fma(wo[a][c], dl, s1); }
+            else emit(a, c, var, gg);
+          }
         }
-        WV_ROW_FENCE();
-      }
-    } else {
-      double q[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[a][c] = 0.0;
-      for (int d = 0; d < f.ndims; ++d) {
-        const int sl = slots[f.slot0 + d];
+      };
+      if (!MULTI || f.ndims == 1) {
+        const int sl = slots[f.slot0];
         double xj[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) xj[c] = t.fj[sl * GT + 4 * t.tx + c];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const double xi = t.fi[sl * GT + t.ty + 16 * a];
+          double q[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const double df = xi - xj[c];
-            q[a][c] = fma(df, df, q[a][c]);
+            const double df = xi - xj[c];  // differences first: no cancellation for short lengthscales
+            q[c] = df * df;
+          }
+          row(a, q);
+          WV_ROW_FENCE();
+        }
+      } else {
+        double q[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) q[a][c] = 0.0;
+        for (int d = 0; d < f.ndims; ++d) {
+          const int sl = slots[f.slot0 + d];
+          double xj[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xj[c] = t.fj[sl * GT + 4 * t.tx + c];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const double xi = t.fi[sl * GT + t.ty + 16 * a];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const double df = xi - xj[c];
+              q[a][c] = fma(df, df, q[a][c]);
+            }
           }
         }
-      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) elem(a, c, q[a][c]);
-        WV_ROW_FENCE();
+        for (int a = 0; a < 4; ++a) {
+          row(a, q[a]);
+          WV_ROW_FENCE();
+        }
       }
-    }
+    };
+    if (type == WV_K_SE) rows(std::integral_constant<int, WV_K_SE>{});
+    else if (type == WV_K_M12) rows(std::integral_constant<int, WV_K_M12>{});
+    else if (type == WV_K_M32) rows(std::integral_constant<int, WV_K_M32>{});
+    else rows(std::integral_constant<int, WV_K_M52>{});
     s1 *= fc[2];
   } else if (type == WV_K_PERIODIC) {
     // t = -sum_d (b sin(pi (x_i - x_j)/p))^2 with b = kCse / l folded into the ROW-side sin / cos features
-    auto elem = [&](int a, int c, double tt, double q2) {
-      const double e = exp2_64(tt, t.tab);
-      if (MODE == 2) {
-        const double we = wo[a][c] * e;
-        s0 += we;
-        s1 = fma(we, tt, s1);
-        s2 = fma(we, q2, s2);
-      } else emit(a, c, var, e);
+    auto row = [&](int a, const double (&tt)[4], const double (&q2)[4]) __attribute__((always_inline)) {
+      double e[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) e[c] = exp2_64(tt[c], t.tab);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (MODE == 2) {
+          const double we = wo[a][c] * e[c];
+          s0 += we;
+          s1 = fma(we, tt[c], s1);
+          s2 = fma(we, q2[c], s2);
+        } else emit(a, c, var, e[c]);
+      }
     };
     if (!MULTI || f.ndims == 1) {
       const int ss = slots[f.slot0], sc = slots[f.slot0 + 1], sr = slots[f.slot0 + 2];
@@ -451,13 +489,15 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
       for (int a = 0; a < 4; ++a) {
         const double si = t.fi[ss * GT + t.ty + 16 * a], ci = t.fi[sc * GT + t.ty + 16 * a];
         const double xi = MODE == 2 ? t.fi[sr * GT + t.ty + 16 * a] : 0.0;
+        double tr[4], q2[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const double sn = fma(si, cj[c], -(ci * sj[c]));
-          double q2 = 0.0;
-          if (MODE == 2) q2 = (xi - xj[c]) * sn * fma(ci, cj[c], si * sj[c]);
-          elem(a, c, -(sn * sn), q2);
+          q2[c] = 0.0;
+          if (MODE == 2) q2[c] = (xi - xj[c]) * sn * fma(ci, cj[c], si * sj[c]);
+          tr[c] = -(sn * sn);
         }
+        row(a, tr, q2);
         WV_ROW_FENCE();
       }
     } else {
@@ -489,8 +529,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) elem(a, c, tt[a][c], q2[a][c]);
+        row(a, tt[a], q2[a]);
         WV_ROW_FENCE();
       }
     }
@@ -561,7 +600,7 @@ __device__ inline void factor_tile(const DevFactor& f, const double* __restrict_
 // sum over (unmasked) terms of the product of their factors, on the thread's 4 x 4 elements
 // (MULTI = false: every factor acts on one column - the paths that keep 4 x 4 distance arrays are not instantiated)
 template <bool MULTI = true>
-__device__ inline void kernel_sum_tile(const DevSpec* __restrict__ sp, const TileCtx& t, uint64_t term_mask,
+__device__ __forceinline__ void kernel_sum_tile(const DevSpec* __restrict__ sp, const TileCtx& t, uint64_t term_mask,
                                        double (&sum)[4][4]) {
   const int16_t* slots = sp->fslots;
   double prod[4][4], dummy_s[3];
@@ -611,7 +650,7 @@ constexpr int GRAM_TPW = 2;  // tiles per workgroup (the exp table is staged onc
 
 // MASKED: missing outputs (row masks per output column), see trace_kernel.  MULTI = false: every factor of every
 // structure of the problem acts on ONE column (what full_kernel_build produces) - fewer live registers, more waves.
-// W4: held to 128 VGPRs (4 waves per SIMD, ~31 VGPRs spilled) instead of 3 waves - WV_GRAM_WAVES picks, scheduling only.
+// W4: held to 128 VGPRs (4 waves per SIMD, 23 VGPRs spilled) instead of 3 waves - diagnostic build only (WV_GRAM_WAVES=4).
 template <typename R, bool MASKED, bool MULTI, bool W4 = false>
 __global__ __launch_bounds__(256, W4 ? 4 : 3) void gram_kernel(const DevSpec* __restrict__ specs,
                                                    const int32_t* __restrict__ slot_spec,
@@ -957,8 +996,9 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
                      p.dtheta, Kall, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.ntiles(), tpw, write_upper, term_mask, \
                      diag, p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol, p.dmask)
   static const bool force_multi = [] { const char* e = experiment_env("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
-  // (measured, 512 fits at N = 2048, same box: 7.02 ms at 3 waves per SIMD, 6.69 at 4 with 31 VGPRs spilled)
-  static const int waves = [] { const char* e = experiment_env("WV_GRAM_WAVES"); return e ? atoi(e) : 4; }();
+  // (512 fits at N = 2048, same box, round 4: 5.14 ms at 3 waves per SIMD - 150 VGPRs, nothing spilled - and 5.29 at 4
+  //  with 23 VGPRs spilled, which also cost 6.7 GB of scratch traffic per launch in round 3: three waves)
+  static const int waves = [] { const char* e = experiment_env("WV_GRAM_WAVES"); return e ? atoi(e) : 3; }();
   const bool multi = p.any_multidim || force_multi;
   if (p.dmask) {
     if (multi) { WV_GRAM_LAUNCH(true, true); } else { WV_GRAM_LAUNCH(true, false); }
@@ -1026,8 +1066,8 @@ void launch_trace(Problem& p, hipStream_t st, int slot0, int nb) {
   p.timer.begin(st, ST_TRACE);
   static const bool force_multi = [] { const char* e = experiment_env("WV_TRACE_MULTI"); return e && atoi(e) != 0; }();
   const bool multi = p.any_multidim || force_multi;
-  // (512 fits at N = 2048, same box: general kernel 7.4 ms; without the product paths 7.03 at 3 waves per SIMD - 140
-  // VGPRs, nothing spilled - and 6.68 at 4 waves - 128 VGPRs, 10 spilled; WV_TRACE_WAVES=3 selects the former)
+  // (512 fits at N = 2048, same box, round 4: without the product paths 6.34 ms at 3 waves per SIMD - 131 VGPRs, nothing
+  // spilled - and 5.88 at 4 waves - 128 VGPRs, 2 spilled; WV_TRACE_WAVES=3 selects the former in the diagnostic build)
   static const int waves = [] { const char* e = experiment_env("WV_TRACE_WAVES"); return e ? atoi(e) : 4; }();
   if (!p.f32 && !multi && !p.any_product && !p.dmask) {  // sums of single-column factors, float64, no missing outputs
     if (waves == 4) trace_launch<double, false, false, false, true>(p, st, p.Kbuf, slot0, nb);
