@@ -113,6 +113,12 @@ def test_prune_candidates():
     assert ks.prune_candidates("lin[1]", K.Lin(active_dims=[1]), []) == {}
     lone = ks.prune_candidates("categorical[2]*lin[1]", k.kernels[0], existing=["lin[1]"])
     assert list(lone) == ["categorical[2]"]
+    # where a product's factor lands among the remaining terms: behind them when their name sorts first or EQUALS the
+    # factor's label (the argsort of the two names at model_search.py:2933-2934), in front otherwise
+    k2 = K.Sum([K.Lin(active_dims=[2]), K.Product([K.Periodic(K.SquaredExponential(active_dims=[0])), K.Lin(active_dims=[2])])])
+    c2 = ks.prune_candidates("lin[2]+periodic[0]*lin[2]", k2, existing=[])
+    assert list(c2) == ["periodic[0]*lin[2]", "lin[2]+periodic[0]", "lin[2]+lin[2]"]
+    assert len(c2["lin[2]+lin[2]"].kernels) == 2
 
 
 def _drive(table, **kw):

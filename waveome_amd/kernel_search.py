@@ -40,7 +40,7 @@ import numpy as np
 from . import kernels as K
 from . import parallel
 from .spec import ModelSpec
-from .utilities import calc_bic, check_if_model_exists, restart_points
+from .utilities import calc_bic, restart_points
 
 
 # ---------------------------------------------------------------------------------------------
@@ -114,9 +114,18 @@ class _Form:
 
     # -- rule 1: add a term.  The new term goes behind the whole structure if the structure's name sorts before the
     #    new label, else in front of it.
-    def plus(self, label, kernel):
+    #    (`ties_behind`: the pruning step's variant of the rule - a structure whose name EQUALS the label also stays in
+    #    front (an argsort of the two names, model_search.py:2933-2934); an empty structure is just the new term.)
+    def plus(self, label, kernel, ties_behind=False):
         new = [(label, kernel)]
-        return _Form(self.terms + [new] if self.name < label else [new] + self.terms)
+        if not self.terms:
+            return _Form([new])
+        behind = self.name <= label if ties_behind else self.name < label
+        return _Form(self.terms + [new] if behind else [new] + self.terms)
+
+    def without(self, i):
+        """The structure without its i-th additive term (possibly empty)."""
+        return _Form([t for j, t in enumerate(self.terms) if j != i])
 
     # -- rule 2: multiply term i by a factor.  Two-way interactions only; inside the product the factor whose label
     #    sorts first leads.  If the existing factor leads the product stays where the term was; if the new factor
@@ -233,43 +242,25 @@ def loc_kernel_candidates(n_features: int, kern_list: Sequence, base_kern=None, 
 
 
 def prune_candidates(best_name: str, best_kernel, existing: Iterable[str]) -> Dict[str, object]:
-    """Structures `prune_best_model2` / `prune_prod_kernel` would refit (model_search.py:2778-2984)."""
-    existing = list(existing)
+    """Structures `prune_best_model2` / `prune_prod_kernel` would refit (model_search.py:2778-2984), on the same `_Form`
+    the search steps use: every additive term is dropped once (`without`); a product term is instead replaced by each of
+    its factors in turn, the factor placed against the remaining terms by the pruning step's own rule (`plus` with ties
+    going behind).  A single base kernel has nothing to prune; a lone product is split into its factors.  Every candidate
+    restarts from 1.0 (:2857-2858); structures fitted before are not proposed again."""
+    seen = existing if isinstance(existing, _Seen) else _Seen(existing)
+    best = _Form.parse(best_kernel, best_name)
     out: Dict[str, object] = {}
-    kernel_names = best_name.split("+")
-    if len(kernel_names) <= 1 and "*" not in kernel_names[0]:
+    if len(best.terms) == 1 and len(best.terms[0]) == 1:
         return out
-    comps = list(best_kernel.kernels) if best_kernel.name == "sum" else [best_kernel]
-    for i in range(len(kernel_names)):
-        others_name = "+".join(x for j, x in enumerate(kernel_names) if j != i)
-        others = [copy.deepcopy(k_) for j, k_ in enumerate(comps) if j != i]
-        if "*" in kernel_names[i]:
-            prod = comps[i]
-            if prod.name != "product":
-                continue
-            parts = kernel_names[i].split("*")
-            for j, piece in enumerate(prod.kernels):
-                if j >= len(parts):
-                    break
-                piece = copy.deepcopy(piece)
-                if others_name == "":
-                    name, cand = parts[j], piece
-                else:
-                    if others_name <= parts[j]:
-                        name, ks = others_name + "+" + parts[j], [copy.deepcopy(o) for o in others] + [piece]
-                    else:
-                        name, ks = parts[j] + "+" + others_name, [piece] + [copy.deepcopy(o) for o in others]
-                    cand = K.Sum(ks)
-                if check_if_model_exists(name, existing):
-                    continue
-                _reset_trainable(cand)
-                out[name] = cand
-            continue
-        cand = K.Sum(others) if len(others) > 1 else others[0]
-        if check_if_model_exists(others_name, existing):
-            continue
-        _reset_trainable(cand)
-        out[others_name] = cand
+    for i, term in enumerate(best.terms):
+        rest = best.copy().without(i)
+        if len(term) == 1:
+            forms = [rest] if rest.terms else []
+        else:
+            forms = [rest.copy().plus(label, copy.deepcopy(k), ties_behind=True) for label, k in best.copy().terms[i]]
+        for form in forms:
+            if form.name not in seen:
+                out[form.name] = form.kernel()
     return out
 
 
