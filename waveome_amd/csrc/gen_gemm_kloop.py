@@ -186,31 +186,41 @@ def frag_reads(la, lb, I, J, s, buf, ard="%[ard]", brd="%[brd{}]"):
     return a_ops, b_ops
 
 
-def mfma_list(I, J, buf):
+def frag_rows(I, j, lower):
+    """A fragments that meet B column set j: all of I, or - `lower`, a wave on the diagonal of a lower-only product -
+    only the 16 x 16 accumulator blocks on and below the diagonal of its 64 x 64 block (i >= j)."""
+    return [i for i in range(*I) if not lower or i >= j]
+
+
+def mfma_list(I, J, buf, lower=False):
     out = []
     for j in range(*J):
         for r in range(4):
-            for i in range(*I):
+            for i in frag_rows(I, j, lower):
                 out.append(lambda st, i=i, j=j, r=r: st.mfma(i, j, r, buf))
     return out
 
 
-def last_use_index(I, J):
+def last_use_index(I, J, lower=False):
     """index (within the k-step's MFMA list) of the last MFMA reading B value n"""
-    ni = I[1] - I[0]
     idx = {}
     m = 0
     for j in range(*J):
         for r in range(4):
-            m += ni
+            m += len(frag_rows(I, j, lower))
             idx[4 * j + r] = m - 1
     return idx
 
 
-def gen_run(la, lb, write_slot0=34, bar_slot=12):
-    """The rotated loop over n full chunks."""
-    I, J = (0, 4), (0, 4)
-    lu = last_use_index(I, J)
+def gen_run(la, lb, J=(0, 4), lower=False, oneop=False, bar_slot=12):
+    """The rotated loop over n full chunks.  J / lower: the two wave roles on a DIAGONAL tile of a square lower-only
+    product (wv_gemm.hip, TRIOPT): `lower` = the wave's own 64 x 64 block lies on the diagonal (40 MFMAs per k-step), J =
+    (0, 2) = the wave owns 32 columns of the full block below (32 MFMAs).  oneop: both fragment kinds are read from ONE
+    staged operand (A == B, same rows): only the A pieces are loaded and written."""
+    I = (0, 4)
+    lu = last_use_index(I, J, lower)
+    nm = len(mfma_list(I, J, 0, lower))
+    write_slot0 = nm // 2 + 2
 
     def body(st, record=None):
         # k-steps 0..2: fetch the next k-step of the same stage; stage the next chunk
@@ -221,25 +231,26 @@ def gen_run(la, lb, write_slot0=34, bar_slot=12):
             if s == 0:   # the next chunk's operand tiles: eight 16-byte pieces per thread
                 for q in range(4):
                     side.append((4 * q + 2, lambda st, q=q: st.gload(vs(q), f"%[oa{q}]", f"s[{S_PA}:{S_PA + 1}]")))
-                for q in range(4):
+                for q in range(0 if oneop else 4):
                     side.append((4 * (q + 4) + 2, lambda st, q=q: st.gload(vs(q + 4), f"%[ob{q}]", f"s[{S_PB}:{S_PB + 1}]")))
             if s == 1:   # chunk bases of the chunk after
                 side.append((2, lambda st: st.emit(f"s_add_u32 s{S_PA}, s{S_PA}, %[sal]")))
                 side.append((6, lambda st: st.emit(f"s_addc_u32 s{S_PA + 1}, s{S_PA + 1}, %[sah]")))
-                side.append((10, lambda st: st.emit(f"s_add_u32 s{S_PB}, s{S_PB}, %[sbl]")))
-                side.append((14, lambda st: st.emit(f"s_addc_u32 s{S_PB + 1}, s{S_PB + 1}, %[sbh]")))
+                if not oneop:
+                    side.append((10, lambda st: st.emit(f"s_add_u32 s{S_PB}, s{S_PB}, %[sbl]")))
+                    side.append((14, lambda st: st.emit(f"s_addc_u32 s{S_PB + 1}, s{S_PB + 1}, %[sbh]")))
             if s == 2:
                 for q in range(4):
                     side.append((write_slot0 + 4 * q, lambda st, q=q: st.ds_write("%[awr]", vs(q), q * WR_STRIDE)))
-                for q in range(4):
+                for q in range(0 if oneop else 4):
                     side.append((write_slot0 + 4 * (q + 4), lambda st, q=q: st.ds_write("%[bwr]", vs(q + 4), q * WR_STRIDE)))
-            kstep_stream(st, mfma_list(I, J, buf), side)
+            kstep_stream(st, mfma_list(I, J, buf, lower), side)
         # k-step 3: toggle the stage, barrier, fetch k-step 0 of the next chunk from the other stage
         buf = 1
         side = []
         tog = [f"v_add_u32 %[ard], s{S_D}, %[ard]"] + [f"v_add_u32 %[brd{r}], s{S_D}, %[brd{r}]" for r in range(4)] + \
-              [f"v_subrev_u32 %[awr], s{S_D}, %[awr]", f"v_subrev_u32 %[bwr], s{S_D}, %[bwr]",
-               f"s_sub_u32 s{S_D}, 0, s{S_D}", f"s_sub_u32 s{S_N}, s{S_N}, 1"]
+              [f"v_subrev_u32 %[awr], s{S_D}, %[awr]"] + ([] if oneop else [f"v_subrev_u32 %[bwr], s{S_D}, %[bwr]"]) + \
+              [f"s_sub_u32 s{S_D}, 0, s{S_D}", f"s_sub_u32 s{S_N}, s{S_N}, 1"]
         for t, line in enumerate(tog):
             side.append((t, lambda st, line=line: st.emit(line)))
 
@@ -255,7 +266,7 @@ def gen_run(la, lb, write_slot0=34, bar_slot=12):
             side.append((bar_slot + 1, fn))
         for n, fn in b_ops[1:]:
             side.append((max(lu[n], bar_slot + 1), fn))
-        kstep_stream(st, mfma_list(I, J, buf), side)
+        kstep_stream(st, mfma_list(I, J, buf, lower), side)
 
     # order of the reads behind the barrier = order of the prologue's reads (the loop head must see the same LGKM
     # history whichever way it is entered)
@@ -263,7 +274,7 @@ def gen_run(la, lb, write_slot0=34, bar_slot=12):
     mark = []
     body(probe, mark)
     pro_reads = [l for l in probe.lines[mark[0]:] if l.startswith("ds_read")]
-    assert len(pro_reads) == 20
+    assert len(pro_reads) == (I[1] - I[0]) + 4 * (J[1] - J[0])
     pro = Stream()             # the prologue: the same reads from a drained counter
     pro.drain_lgkm()
     for l in pro_reads:
@@ -282,10 +293,10 @@ def gen_run(la, lb, write_slot0=34, bar_slot=12):
     assert (second.issued, second.known, second.ready) == (pro.issued, pro.known, pro.ready), "loop head state differs"
     body(second)
     assert first.lines == second.lines, "loop-carried wait state is not a fixed point"
-    assert first.n_mfma == 256
+    assert first.n_mfma == 4 * nm
 
-    lines = [f"s_mov_b64 s[{S_PA}:{S_PA + 1}], %[pa]", f"s_mov_b64 s[{S_PB}:{S_PB + 1}], %[pb]",
-             f"s_mov_b32 s{S_N}, %[n]", f"s_mov_b32 s{S_D}, %[d]"]
+    lines = [f"s_mov_b64 s[{S_PA}:{S_PA + 1}], %[pa]"] + ([] if oneop else [f"s_mov_b64 s[{S_PB}:{S_PB + 1}], %[pb]"]) + \
+            [f"s_mov_b32 s{S_N}, %[n]", f"s_mov_b32 s{S_D}, %[d]"]
     lines += pro.lines
     lines.append("L_wv_kloop_%=:")
     lines += first.lines
@@ -294,12 +305,12 @@ def gen_run(la, lb, write_slot0=34, bar_slot=12):
     return lines
 
 
-def gen_chunk(la, lb, I, J, stage):
+def gen_chunk(la, lb, I, J, stage, lower=False, oneop=False):
     """One chunk, fragment ranges I x J, pipelined inside the chunk, barrier at the end."""
     st = Stream()
     st.drain_lgkm()    # (whatever the compiler's code before the statement left in flight)
-    lu = last_use_index(I, J)
-    nm = (I[1] - I[0]) * (J[1] - J[0]) * 4
+    lu = last_use_index(I, J, lower)
+    nm = len(mfma_list(I, J, 0, lower))
     a_ops, b_ops = frag_reads(la, lb, I, J, 0, 0)
     # prologue order: what the first MFMAs need first
     for n, fn in b_ops[:1]:
@@ -319,14 +330,14 @@ def gen_chunk(la, lb, I, J, stage):
         if stage and s == 0:
             for q in range(4):
                 side.append((-1, lambda st, q=q: st.gload(vs(q), f"%[oa{q}]", "%[pa]")))
-            for q in range(4):
+            for q in range(0 if oneop else 4):
                 side.append((-1, lambda st, q=q: st.gload(vs(q + 4), f"%[ob{q}]", "%[pb]")))
         if stage and s == 3:
             for q in range(4):
                 side.append((nm // 2, lambda st, q=q: st.ds_write("%[awr]", vs(q), q * WR_STRIDE)))
-            for q in range(4):
+            for q in range(0 if oneop else 4):
                 side.append((nm // 2, lambda st, q=q: st.ds_write("%[bwr]", vs(q + 4), q * WR_STRIDE)))
-        kstep_stream(st, mfma_list(I, J, buf), side)
+        kstep_stream(st, mfma_list(I, J, buf, lower), side)
     assert st.n_mfma == 4 * nm
     st.drain_lgkm()
     st.emit("s_barrier")
@@ -343,8 +354,8 @@ def c_string(lines):
     return "      WV_KLOOP_ACC_PRELUDE\n" + "\n".join(f'      "{l}\\n\\t"' for l in lines)
 
 
-def emit_run(name, la, lb):
-    lines = gen_run(la, lb)
+def emit_run(name, la, lb, **kw):
+    lines = gen_run(la, lb, **kw)
     return f"""
 // {len(lines)} instructions; loop body {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs
 __device__ __forceinline__ void {name}({ACC_ARGS}, uint32_t ard, uint32_t brd0, uint32_t brd1, uint32_t brd2,
@@ -363,8 +374,8 @@ __device__ __forceinline__ void {name}({ACC_ARGS}, uint32_t ard, uint32_t brd0, 
 """
 
 
-def emit_chunk(name, la, lb, I, J, stage):
-    lines = gen_chunk(la, lb, I, J, stage)
+def emit_chunk(name, la, lb, I, J, stage, **kw):
+    lines = gen_chunk(la, lb, I, J, stage, **kw)
     if stage:
         return f"""
 __device__ __forceinline__ void {name}({ACC_ARGS}, uint32_t ard, uint32_t brd0, uint32_t brd1, uint32_t brd2,
@@ -460,6 +471,12 @@ def main(out_path):
                         "jlo": ((0, 4), (0, live)), "jhi": ((0, 4), (4 - live, 4))}[fam]
                 for stage in (True, False):
                     out.append(emit_chunk(f"chunk_{tag}_{fam}{live}_{'stage' if stage else 'last'}", la, lb, I, J, stage))
+    # diagonal tiles of a square lower-only product (TRIOPT + ONEOP in wv_gemm.hip): one staged operand, two wave roles
+    out.append("// ---- diagonal tiles of a square lower-only product: ONE staged operand (the B pieces / pointers of the common")
+    out.append("// signature are unused); low = a wave on the diagonal (accumulator blocks i >= j), half = 32 columns of the block below")
+    for role, kw in (("low", dict(J=(0, 4), lower=True)), ("half", dict(J=(0, 2), lower=False))):
+        out.append(emit_run(f"run_ss_{role}1", ks, ks, oneop=True, **kw))
+        out.append(emit_chunk(f"chunk_ss_{role}1_last", ks, ks, (0, 4), kw["J"], False, lower=kw["lower"], oneop=True))
     out.append("} }  // namespace wv::kloop")
     with open(out_path, "w") as f:
         f.write("\n".join(out) + "\n")
@@ -476,7 +493,7 @@ def main(out_path):
 import re as _re
 
 
-def verify(lines, la, lb, I, J, loop_iters=1):
+def verify(lines, la, lb, I, J, loop_iters=1, lower=False):
     head = lines.index("L_wv_kloop_%=:") if "L_wv_kloop_%=:" in lines else None
     if head is not None:
         tail = next(k for k, l in enumerate(lines) if l.startswith("s_cbranch_scc1"))
@@ -535,7 +552,7 @@ def verify(lines, la, lb, I, J, loop_iters=1):
             assert regs.get(a) == ("A", i, s, chunk & 1), (l, regs.get(a), ("A", i, s, chunk & 1))
             assert regs.get(b) == ("B", j, r, s, chunk & 1), (l, regs.get(b), ("B", j, r, s, chunk & 1))
             acc_steps[c] = n + 1
-    want = {acc(i, j, r) for i in range(*I) for j in range(*J) for r in range(4)}
+    want = {acc(i, j, r) for j in range(*J) for i in frag_rows(I, j, lower) for r in range(4)}
     assert set(acc_steps) == want and all(v == 4 * loop_iters for v in acc_steps.values()), "accumulators / k-steps"
 
 
@@ -548,6 +565,10 @@ def _self_check():
                     [((0, 4), (0, v)) for v in (1, 2, 3)] + [((0, 4), (4 - v, 4)) for v in (1, 2, 3)]:
             for stage in (True, False):
                 verify(gen_chunk(la, lb, I, J, stage), la, lb, I, J)
+    for J, lower in (((0, 4), True), ((0, 2), False)):
+        for iters in (1, 2, 5):
+            verify(gen_run(ks, ks, J=J, lower=lower, oneop=True), ks, ks, (0, 4), J, iters, lower=lower)
+        verify(gen_chunk(ks, ks, (0, 4), J, False, lower=lower, oneop=True), ks, ks, (0, 4), J, lower=lower)
 
 
 if __name__ == "__main__":
