@@ -34,6 +34,15 @@ int32_t wv_dbg_copy_rate(wv_ctx* ctx, int64_t bytes, int32_t iters, double* gbps
  * chunk in LDS, [2] end of the K loop, [3] end of the epilogue. */
 int32_t wv_dbg_gemm_stamps(unsigned long long* out);
 
+/* exp2_64 (wv_gram.hip: 2^(t / 64), t <= 0) and three cheaper forms of it (variant 1: 3-address v_fma_f64 with SGPR
+ * coefficients; 2: + rint / convert by the 1.5 * 2^52 shift; 3: + ldexp as an add into the exponent field): rate in
+ * 1e9 evaluations per second with `waves_per_simd` waves per SIMD on every CU, arguments t0 - k dt; and the number of
+ * arguments of t_host[n] on which a variant's bits differ from variant 0's (first_bad3_out: t, shipped, variant).
+ * tools/probe_exp_rate.py, profiles/r04_exp_rate.txt. */
+int32_t wv_dbg_exp_rate(int32_t variant, int32_t iters, int32_t waves_per_simd, double t0, double dt,
+                        double* gexp_per_s_out);
+int32_t wv_dbg_exp_check(int32_t variant, const double* t_host, int64_t n, int64_t* n_bad_out, double* first_bad3_out);
+
 #ifdef __cplusplus
 }
 #endif
