@@ -493,3 +493,40 @@ def test_deviance_explained_rows_with_zero_null_deviance():
     null_dev, model_dev = calc_deviance_explained(None, data=(None, y), model_mu=mu, aggregate=False,
                                                   return_deviance_explained=False)
     np.testing.assert_allclose(null_dev * np.var(y), [1, 0, 1, 0], atol=1e-12)
+
+
+def test_gemm_kloop_generator_proves_its_streams_and_the_model_catches_a_broken_one(tmp_path):
+    """The hand-scheduled GEMM K loop is generated (waveome_amd/csrc/gen_gemm_kloop.py) and every emitted stream is replayed
+    against a model of the LGKM queue before it is written (operands landed behind a counted wait with at most 15
+    operations outstanding, right fragment / k-step / chunk for every accumulator).  Here: the self-check passes for every
+    stream of the build, the file it writes is the one the build uses, and the model does reject a stream whose wait was
+    loosened or whose fragment offset is wrong - i.e. it would have caught the two bugs round 4 actually had."""
+    import importlib.util
+
+    src = os.path.join(ROOT, "waveome_amd", "csrc", "gen_gemm_kloop.py")
+    spec = importlib.util.spec_from_file_location("gen_gemm_kloop", src)
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    g._self_check()
+    out = tmp_path / "kloop.inc"
+    g.main(str(out))
+    built = os.path.join(ROOT, "waveome_amd", "csrc", "wv_gemm_kloop.inc")
+    if os.path.exists(built):
+        assert out.read_text() == open(built).read()
+    ks = g.Layout(False)
+    for kw, J, lower in ((dict(), (0, 4), False), (dict(J=(0, 4), lower=True, oneop=True), (0, 4), True),
+                         (dict(J=(0, 2), oneop=True), (0, 2), False)):
+        lines = g.gen_run(ks, ks, **kw)
+        g.verify(lines, ks, ks, (0, 4), J, 3, lower=lower)
+        # a counted wait loosened by one: some MFMA reads a fragment that has not landed
+        k = next(i for i, l in enumerate(lines) if l.startswith("s_waitcnt lgkmcnt(") and not l.endswith("(0)") and i > 40)
+        n = int(lines[k].split("(")[1].rstrip(")"))
+        broken = lines[:k] + [f"s_waitcnt lgkmcnt({n + 1})"] + lines[k + 1:]
+        with pytest.raises(AssertionError):
+            g.verify(broken, ks, ks, (0, 4), J, 3, lower=lower)
+        # a fragment read from the wrong k-step
+        k = next(i for i, l in enumerate(lines) if l.startswith("ds_read_b64") and "%[ard]" in l and i > 60)
+        off = int(lines[k].split("offset:")[1])
+        broken = lines[:k] + [lines[k].replace(f"offset:{off}", f"offset:{(off + ks.kstep) % (4 * ks.kstep)}")] + lines[k + 1:]
+        with pytest.raises(AssertionError):
+            g.verify(broken, ks, ks, (0, 4), J, 3, lower=lower)
