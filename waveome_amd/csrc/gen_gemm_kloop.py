@@ -52,7 +52,10 @@ WR_STRIDE = 4608     # LDS byte stride between a thread's four staging pieces (b
 
 
 class Layout:
-    def __init__(self, kcontig):
+    """LDS image of one operand stage.  spread: a wave's fragments are every OTHER 16-row group of the 128-row panel
+    (rows 16 w + 32 f; wv_gemm.hip, SPREAD) instead of four consecutive ones."""
+
+    def __init__(self, kcontig, spread=False):
         self.kc = kcontig
         if kcontig:      # [rows][18]
             self.frag = 16 * 18 * 8   # next 16 rows
@@ -60,6 +63,8 @@ class Layout:
         else:            # [16][rows + 16], rows = 128
             self.frag = 16 * 8
             self.kstep = 4 * 144 * 8
+        if spread:
+            self.frag *= 2
 
 
 def acc(i, j, r):
@@ -403,7 +408,8 @@ __device__ __forceinline__ void {name}({ACC_ARGS}, uint32_t ard, uint32_t brd0, 
 
 
 def main(out_path):
-    ks, kc = Layout(False), Layout(True)
+    ks, kc = Layout(False, spread=True), Layout(True, spread=True)
+    ks_block = Layout(False)   # the diagonal-tile roles keep the 64 x 64 corner per wave
     out = ["// GENERATED by gen_gemm_kloop.py - do not edit.  Hand-scheduled gfx950 ISA of the float64 GEMM K loop;",
            "// register layout, pipeline and wait discipline are described in the generator.",
            "#pragma once",
@@ -471,12 +477,16 @@ def main(out_path):
                         "jlo": ((0, 4), (0, live)), "jhi": ((0, 4), (4 - live, 4))}[fam]
                 for stage in (True, False):
                     out.append(emit_chunk(f"chunk_{tag}_{fam}{live}_{'stage' if stage else 'last'}", la, lb, I, J, stage))
+    # the trailing update's off-diagonal tiles (uniform contraction range, no partial chunks): a 64 x 64 corner per wave
+    out.append("// ---- 64 x 64 corner per wave (not spread): the trailing update's lower tiles")
+    out.append(emit_run("run_ss_blk", ks_block, ks_block))
+    out.append(emit_chunk("chunk_ss_full_last_blk", ks_block, ks_block, (0, 4), (0, 4), False))
     # diagonal tiles of a square lower-only product (TRIOPT + ONEOP in wv_gemm.hip): one staged operand, two wave roles
     out.append("// ---- diagonal tiles of a square lower-only product: ONE staged operand (the B pieces / pointers of the common")
     out.append("// signature are unused); low = a wave on the diagonal (accumulator blocks i >= j), half = 32 columns of the block below")
     for role, kw in (("low", dict(J=(0, 4), lower=True)), ("half", dict(J=(0, 2), lower=False))):
-        out.append(emit_run(f"run_ss_{role}1", ks, ks, oneop=True, **kw))
-        out.append(emit_chunk(f"chunk_ss_{role}1_last", ks, ks, (0, 4), kw["J"], False, lower=kw["lower"], oneop=True))
+        out.append(emit_run(f"run_ss_{role}1", ks_block, ks_block, oneop=True, **kw))
+        out.append(emit_chunk(f"chunk_ss_{role}1_last", ks_block, ks_block, (0, 4), kw["J"], False, lower=kw["lower"], oneop=True))
     out.append("} }  // namespace wv::kloop")
     with open(out_path, "w") as f:
         f.write("\n".join(out) + "\n")
@@ -558,7 +568,8 @@ def verify(lines, la, lb, I, J, loop_iters=1, lower=False):
 
 def _self_check():
     ks, kc = Layout(False), Layout(True)
-    for la, lb in ((ks, ks), (kc, ks)):
+    ksx, kcx = Layout(False, spread=True), Layout(True, spread=True)
+    for la, lb in ((ksx, ksx), (kcx, ksx), (ks, ks), (kc, ks)):
         for iters in (1, 2, 5):
             verify(gen_run(la, lb), la, lb, (0, 4), (0, 4), iters)
         for I, J in [((0, 4), (0, 4))] + [((0, v), (0, 4)) for v in (1, 2, 3)] + [((4 - v, 4), (0, 4)) for v in (1, 2, 3)] + \
