@@ -127,6 +127,8 @@ PROBE_SIGNATURES = {
     "wv_dbg_mfma4_probe": (C.c_int32, [_vp, _ip]),
     "wv_dbg_copy_rate": (C.c_int32, [_vp, C.c_int64, C.c_int32, _dp]),
     "wv_dbg_gemm_stamps": (C.c_int32, [C.POINTER(C.c_uint64)]),
+    "wv_dbg_exp_rate": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp]),
+    "wv_dbg_exp_check": (C.c_int32, [C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64), _dp]),
 }
 
 _lib = None
