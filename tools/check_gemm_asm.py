@@ -5,8 +5,10 @@ import os
 import sys
 
 sys.path.insert(0, ".")
-os.environ.setdefault("WV_BN_FILL", "0")        # 128 x 128 tiles whatever the launch size
-os.environ.setdefault("WV_TRI_SPLIT_MIN", "1")
+SMALL_ONLY = len(sys.argv) > 1 and sys.argv[1] == "small"   # `small`: default tile thresholds - three fits run on the small 64 x 64 tile
+if not SMALL_ONLY:
+    os.environ.setdefault("WV_BN_FILL", "0")        # 128 x 128 tiles whatever the launch size
+    os.environ.setdefault("WV_TRI_SPLIT_MIN", "1")
 import numpy as np
 
 import _probes_lib  # noqa: F401
@@ -17,7 +19,7 @@ from waveome_amd.engine import Context, Problem
 ctx = Context(0)
 rng = np.random.default_rng(5)
 bad = 0
-for (nb, M, N, Kd, akc) in [(9, 256, 384, 208, False), (9, 256, 384, 208, True), (3, 192, 320, 80, False), (2, 128, 128, 16, True),
+for (nb, M, N, Kd, akc) in [] if SMALL_ONLY else [(9, 256, 384, 208, False), (9, 256, 384, 208, True), (3, 192, 320, 80, False), (2, 128, 128, 16, True),
                             (2, 130, 126, 48, False), (17, 640, 512, 1024, False)]:
     A = rng.normal(size=(nb, M, Kd))
     B = rng.normal(size=(nb, N, Kd))
@@ -58,7 +60,7 @@ forms = [("S", True, 1.0, 0.0, 0, 0, 2, 1, 0, False), ("T", False, 1.0, 0.0, 0, 
          ("M21", False, -1.0, 0.0, 0, 0, 1, 2, 0, False), ("M21 plain output", False, -1.0, 0.0, 0, 0, 1, 0, 0, False),
          ("both outputs, full k", False, -1.0, 0.0, 0, 0, 0, 2, 0, False), ("update", False, -1.0, 1.0, 1, 0, 0, 0, 2, True),
          ("M'M", False, 1.0, 0.0, 1, 1, 0, 0, 1, True)]
-for (name, a_kc, alpha, beta, tri, klo, khi, tout, tag, same) in forms:
+for (name, a_kc, alpha, beta, tri, klo, khi, tout, tag, same) in ([] if SMALL_ONLY else forms):
     for (nb, M) in ((3, 128), (9, 256), (2, 512), (16, 384)):
         N = Kd = M
         A = rng.normal(size=(nb, M, Kd) if a_kc else (nb, Kd, M))
@@ -90,7 +92,7 @@ for (name, a_kc, alpha, beta, tri, klo, khi, tout, tag, same) in forms:
         print(line, flush=True)
         bad += (not same_c) or not (err < 1e-10)
 
-for N in (704, 2048):
+for N in ((150, 704, 1500, 2048) if SMALL_ONLY else (704, 2048)):
     X = rng.normal(size=(N, 3))
     Y = np.stack([np.sin(X[:, 0] * (1 + 0.3 * p)) + 0.3 * X[:, 1] + 0.1 * rng.normal(size=N) for p in range(3)], axis=1)
     kern = K.Sum([K.SquaredExponential(active_dims=[0]), K.Matern32(active_dims=[1]),

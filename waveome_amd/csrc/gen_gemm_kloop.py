@@ -94,7 +94,8 @@ def vs(q):
 class Stream:
     """Instruction list + the LGKM / VM counters needed for counted waits."""
 
-    def __init__(self):
+    def __init__(self, regs=None):
+        self.regs = regs     # None: the 128 x 128 kernels' map (module functions va / vb / acc); else an object with those
         self.lines = []
         self.issued = 0      # LGKM operations issued so far
         self.known = 0       # every LGKM operation with index < known is complete
@@ -152,9 +153,10 @@ class Stream:
         self.known = self.issued
 
     def mfma(self, i, j, r, buf):
-        a, b = va(buf, i), vb(4 * j + r)
+        m = self.regs
+        a, b = (m.va(buf, i), m.vb(4 * j + r)) if m else (va(buf, i), vb(4 * j + r))
         self.need([a, b])
-        c = acc(i, j, r)
+        c = m.acc(i, j, r) if m else acc(i, j, r)
         self.emit(f"v_mfma_f64_4x4x4_4b_f64 {c}, {a}, {b}, {c}")
         self.n_mfma += 1
 
@@ -350,6 +352,158 @@ def gen_chunk(la, lb, I, J, stage, lower=False, oneop=False):
     return st.lines
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# The SMALL tile (64 x 64 block tile, the four waves side by side: 64 rows x 16 columns each - few fits in flight and
+# the lowest recursion level): sixteen accumulators per wave, so they stay ordinary VGPR values of the compiler (four
+# 256-bit "+v" operands, named through assembler symbols like the AGPR ones); one statement kind, the rotated run of
+# n >= 1 full staged chunks - single chunks (a tile's last, partial ones) stay hipcc's.
+# ---------------------------------------------------------------------------------------------------------------
+class SmallRegs:
+    VA0, VB0, VS0 = 128, 144, 152      # A fragments double-buffered (16), B ring (8), staging pieces (16): v[128:167]
+
+    @staticmethod
+    def va(buf, i):
+        x = SmallRegs.VA0 + 8 * buf + 2 * i
+        return f"v[{x}:{x + 1}]"
+
+    @staticmethod
+    def vb(n):
+        x = SmallRegs.VB0 + 2 * n
+        return f"v[{x}:{x + 1}]"
+
+    @staticmethod
+    def vs(q):
+        x = SmallRegs.VS0 + 4 * q
+        return f"v[{x}:{x + 3}]"
+
+    @staticmethod
+    def acc(i, j, r):
+        return f"v[WVC{i}+{2 * r}:WVC{i}+{2 * r + 1}]"
+
+
+SMALL_PRELUDE = [f".ifc %[c{k}],v[{b}:{b + 7}]\\n\\t.set WVC{k},{b}\\n\\t.endif" for k in range(4) for b in range(0, 249)]
+S_DB = 90   # B's stage toggle (the two operands' stages differ in size when A is K-contiguous)
+
+
+class SmallLayout:
+    def __init__(self, kcontig):
+        self.kc = kcontig
+        if kcontig:      # [64][18]
+            self.frag, self.kstep, self.wr_stride = 16 * 18 * 8, 4 * 8, 32 * 18 * 8
+        else:            # [16][64 + 16]
+            self.frag, self.kstep, self.wr_stride = 16 * 8, 4 * 80 * 8, 8 * 80 * 8
+
+
+def gen_small_run(la, lb, bar_slot=4):
+    I, J = (0, 4), (0, 1)
+    R = SmallRegs
+    lu = last_use_index(I, J)          # B value r is free after MFMA 4 r + 3
+    a_slots = [0, 1, 2, 5]             # where the next k-step's A fragments are fetched (one side operation per MFMA)
+
+    def reads(s, buf):
+        a_ops = [(i, (lambda st, i=i: st.ds_read(R.va(buf, i), "%[ard]", i * la.frag + s * la.kstep))) for i in range(4)]
+        b_ops = [(r, (lambda st, r=r: st.ds_read(R.vb(r), f"%[brd{r}]", s * lb.kstep))) for r in range(4)]
+        return a_ops, b_ops
+
+    def body(st, record=None):
+        for s in range(3):
+            buf = s & 1
+            a_ops, b_ops = reads(s + 1, buf ^ 1)
+            side = [(a_slots[i], fn) for i, fn in a_ops] + [(lu[r], fn) for r, fn in b_ops]
+            if s == 0:
+                for q in range(2):
+                    side.append((3 + q, lambda st, q=q: st.gload(R.vs(q), f"%[oa{q}]", f"s[{S_PA}:{S_PA + 1}]")))
+                for q in range(2):
+                    side.append((6 + q, lambda st, q=q: st.gload(R.vs(q + 2), f"%[ob{q}]", f"s[{S_PB}:{S_PB + 1}]")))
+            if s == 1:
+                side.append((4, lambda st: st.emit(f"s_add_u32 s{S_PA}, s{S_PA}, %[sal]")))
+                side.append((6, lambda st: st.emit(f"s_addc_u32 s{S_PA + 1}, s{S_PA + 1}, %[sah]")))
+                side.append((8, lambda st: st.emit(f"s_add_u32 s{S_PB}, s{S_PB}, %[sbl]")))
+                side.append((10, lambda st: st.emit(f"s_addc_u32 s{S_PB + 1}, s{S_PB + 1}, %[sbh]")))
+            kstep_stream(st, mfma_list(I, J, buf), side)
+        # k-step 3: toggle the stages, barrier, fetch k-step 0 of the next chunk from the other stage
+        buf = 1
+        tog = [f"v_add_u32 %[ard], s{S_D}, %[ard]"] + [f"v_add_u32 %[brd{r}], s{S_DB}, %[brd{r}]" for r in range(4)] + \
+              [f"v_subrev_u32 %[awr], s{S_D}, %[awr]", f"v_subrev_u32 %[bwr], s{S_DB}, %[bwr]",
+               f"s_sub_u32 s{S_D}, 0, s{S_D}", f"s_sub_u32 s{S_DB}, 0, s{S_DB}", f"s_sub_u32 s{S_N}, s{S_N}, 1"]
+        side = []
+        # the next stage's pieces as late as the barrier allows (a chunk is 64 MFMAs - ~1 k cycles - and the global loads of
+        # k-step 0 need most of it); the address toggles ride behind them (this k-step's own reads were issued in k-step 2)
+        for q in range(2):
+            side.append((q, lambda st, q=q: st.ds_write("%[awr]", R.vs(q), q * la.wr_stride)))
+        for q in range(2):
+            side.append((2 + q, lambda st, q=q: st.ds_write("%[bwr]", R.vs(q + 2), q * lb.wr_stride)))
+
+        def barrier(st):
+            for line in tog:
+                st.emit(line)
+            st.drain_lgkm()
+            st.emit("s_barrier")
+            if record is not None:
+                record.append(len(st.lines))
+        side.append((bar_slot, barrier))
+        a_ops, b_ops = reads(0, 0)
+        side.append((bar_slot + 1, b_ops[0][1]))
+        for i, fn in a_ops:
+            side.append((bar_slot + 1, fn))
+        for r, fn in b_ops[1:]:
+            side.append((max(lu[r], bar_slot + 1), fn))
+        kstep_stream(st, mfma_list(I, J, buf), side)
+
+    probe = Stream(R)
+    mark = []
+    body(probe, mark)
+    pro_reads = [l for l in probe.lines[mark[0]:] if l.startswith("ds_read")]
+    assert len(pro_reads) == 8
+    pro = Stream(R)
+    pro.drain_lgkm()
+    for l in pro_reads:
+        dst, addr, off = l.split()[1].rstrip(","), l.split()[2], l.split("offset:")[1]
+        pro.ds_read(dst, addr, off)
+
+    def carry(src, since):
+        st = Stream(R)
+        st.issued, st.known = src.issued - since, max(0, src.known - since)
+        st.ready = {k: v - since for k, v in src.ready.items() if v >= since}
+        return st
+
+    first = carry(pro, 0)
+    body(first)
+    second = carry(first, first.issued - pro.issued)
+    assert (second.issued, second.known, second.ready) == (pro.issued, pro.known, pro.ready), "loop head state differs"
+    body(second)
+    assert first.lines == second.lines, "loop-carried wait state is not a fixed point"
+    assert first.n_mfma == 64
+    lines = [f"s_mov_b64 s[{S_PA}:{S_PA + 1}], %[pa]", f"s_mov_b64 s[{S_PB}:{S_PB + 1}], %[pb]",
+             f"s_mov_b32 s{S_N}, %[n]", f"s_mov_b32 s{S_D}, %[da]", f"s_mov_b32 s{S_DB}, %[db]"]
+    lines += pro.lines
+    lines.append("L_wv_kloop_%=:")
+    lines += first.lines
+    lines += [f"s_cmp_lg_u32 s{S_N}, 0", "s_cbranch_scc1 L_wv_kloop_%=", "s_waitcnt lgkmcnt(0)", "s_nop 15"]
+    return lines
+
+
+def emit_small_run(name, la, lb):
+    lines = gen_small_run(la, lb)
+    text = "      WV_SMALL_ACC_PRELUDE\n" + "\n".join(f'      "{l}\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{k}"' for k in range(SmallRegs.VA0, SmallRegs.VS0 + 16))
+    return f"""
+// {len(lines)} instructions; loop body {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs
+__device__ __forceinline__ void {name}(v8i& c0, v8i& c1, v8i& c2, v8i& c3, uint32_t ard, uint32_t brd0, uint32_t brd1, uint32_t brd2,
+    uint32_t brd3, uint32_t awr, uint32_t bwr, uint32_t oa0, uint32_t oa1, uint32_t ob0, uint32_t ob1, const char* pa,
+    const char* pb, uint32_t sal, uint32_t sah, uint32_t sbl, uint32_t sbh, int n, int da, int db) {{
+  asm volatile(
+{text}
+      : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [ard] "+v"(ard), [brd0] "+v"(brd0), [brd1] "+v"(brd1),
+        [brd2] "+v"(brd2), [brd3] "+v"(brd3), [awr] "+v"(awr), [bwr] "+v"(bwr)
+      : [oa0] "v"(oa0), [oa1] "v"(oa1), [ob0] "v"(ob0), [ob1] "v"(ob1), [pa] "s"(pa), [pb] "s"(pb), [sal] "s"(sal),
+        [sah] "s"(sah), [sbl] "s"(sbl), [sbh] "s"(sbh), [n] "s"(n), [da] "s"(da), [db] "s"(db)
+      : "memory", "scc", "s{S_PA}", "s{S_PA + 1}", "s{S_PB}", "s{S_PB + 1}", "s{S_N}", "s{S_D}", "s{S_DB}", {clob});
+}}
+"""
+
+
 CLOBBER_V = ", ".join(f'"v{k}"' for k in range(VA0, 128))
 ACC_ARGS = "const v32i& c0, const v32i& c1, const v32i& c2, const v32i& c3"
 ACC_OPS = '[c0] "a"(c0), [c1] "a"(c1), [c2] "a"(c2), [c3] "a"(c3)'
@@ -417,8 +571,10 @@ def main(out_path):
            "// assembler-time lookup of the accumulator operands' base registers (directives only, no instructions)",
            "#define WV_KLOOP_ACC_PRELUDE \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in ACC_PRELUDE),
            "#define WV_KLOOP_ACC_PRELUDE_OUT WV_KLOOP_ACC_PRELUDE",
+           "#define WV_SMALL_ACC_PRELUDE \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in SMALL_PRELUDE),
            "namespace wv { namespace kloop {",
            "typedef int v32i __attribute__((ext_vector_type(32)));  // sixteen float64 accumulators in 32 AGPRs",
+           "typedef int v8i __attribute__((ext_vector_type(8)));    // four float64 accumulators of the small tile in 8 VGPRs",
            "// the accumulators come into being here (zeros), in registers of the allocator's choosing ...",
            "__device__ __forceinline__ void zero_acc(v32i& c0, v32i& c1, v32i& c2, v32i& c3) {",
            "  asm volatile(",
@@ -487,6 +643,9 @@ def main(out_path):
     for role, kw in (("low", dict(J=(0, 4), lower=True)), ("half", dict(J=(0, 2), lower=False))):
         out.append(emit_run(f"run_ss_{role}1", ks_block, ks_block, oneop=True, **kw))
         out.append(emit_chunk(f"chunk_ss_{role}1_last", ks_block, ks_block, (0, 4), kw["J"], False, lower=kw["lower"], oneop=True))
+    out.append("// ---- the small 64 x 64 tile (four waves side by side): the rotated run of full staged chunks")
+    out.append(emit_small_run("srun_ss", SmallLayout(False), SmallLayout(False)))
+    out.append(emit_small_run("srun_cs", SmallLayout(True), SmallLayout(False)))
     out.append("} }  // namespace wv::kloop")
     with open(out_path, "w") as f:
         f.write("\n".join(out) + "\n")
@@ -503,7 +662,7 @@ def main(out_path):
 import re as _re
 
 
-def verify(lines, la, lb, I, J, loop_iters=1, lower=False):
+def verify(lines, la, lb, I, J, loop_iters=1, lower=False, small=False):
     head = lines.index("L_wv_kloop_%=:") if "L_wv_kloop_%=:" in lines else None
     if head is not None:
         tail = next(k for k, l in enumerate(lines) if l.startswith("s_cbranch_scc1"))
@@ -550,7 +709,7 @@ def verify(lines, la, lb, I, J, loop_iters=1, lower=False):
         if m and m.group(1) in toggles:
             toggles[m.group(1)] ^= 1
             continue
-        m = _re.match(r"v_mfma_f64_4x4x4_4b_f64 (a\[WVACC(\d)\+(\d+):WVACC\d\+\d+\]), (v\[\d+:\d+\]), (v\[\d+:\d+\]), (a\[\S+\])", l)
+        m = _re.match(r"v_mfma_f64_4x4x4_4b_f64 ([av]\[WV(?:ACC|C)(\d)\+(\d+):WV(?:ACC|C)\d\+\d+\]), (v\[\d+:\d+\]), (v\[\d+:\d+\]), ([av]\[\S+\])", l)
         if m:
             c, a, b = m.group(1), m.group(4), m.group(5)
             assert c == m.group(6)
@@ -562,7 +721,8 @@ def verify(lines, la, lb, I, J, loop_iters=1, lower=False):
             assert regs.get(a) == ("A", i, s, chunk & 1), (l, regs.get(a), ("A", i, s, chunk & 1))
             assert regs.get(b) == ("B", j, r, s, chunk & 1), (l, regs.get(b), ("B", j, r, s, chunk & 1))
             acc_steps[c] = n + 1
-    want = {acc(i, j, r) for j in range(*J) for i in frag_rows(I, j, lower) for r in range(4)}
+    accfn = SmallRegs.acc if small else acc
+    want = {accfn(i, j, r) for j in range(*J) for i in frag_rows(I, j, lower) for r in range(4)}
     assert set(acc_steps) == want and all(v == 4 * loop_iters for v in acc_steps.values()), "accumulators / k-steps"
 
 
@@ -576,6 +736,9 @@ def _self_check():
                     [((0, 4), (0, v)) for v in (1, 2, 3)] + [((0, 4), (4 - v, 4)) for v in (1, 2, 3)]:
             for stage in (True, False):
                 verify(gen_chunk(la, lb, I, J, stage), la, lb, I, J)
+    for la in (SmallLayout(False), SmallLayout(True)):
+        for iters in (1, 2, 5):
+            verify(gen_small_run(la, SmallLayout(False)), la, SmallLayout(False), (0, 4), (0, 1), iters, small=True)
     for J, lower in (((0, 4), True), ((0, 2), False)):
         for iters in (1, 2, 5):
             verify(gen_run(ks, ks, J=J, lower=lower, oneop=True), ks, ks, (0, 4), J, iters, lower=lower)
