@@ -77,6 +77,30 @@ def headline_spec_dict():
     return headline_spec().to_dict()
 
 
+def physical_cores():
+    """(physical cores among the CPUs of this process's affinity mask, cgroup CPU quota in cores or None)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                cores.add(fh.read().strip())
+        except OSError:
+            cores.add(str(c))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, len(cores)), quota
+
+
 def cpu_baseline_measure(X, Y, seconds_budget=24.0):
     """SURVEY 8(d) CPU row, measurement half: the oracle port (NumPy/SciPy -> LAPACK dpotrf/dpotri, every kernel factor
     evaluated once, traces accumulated term by term) on this box's host cores, on a bounded sample of the same
@@ -106,10 +130,14 @@ def cpu_baseline_measure(X, Y, seconds_budget=24.0):
     k_a = int(max(1, min(8, (half - t_first) / max(t_first, 1e-3))))
     dt_a = _cpu_time_evals(spec, X, Y[0], k_a)
     mode_a = {"evals_per_s": k_a / dt_a, "blas_threads": blas_threads, "evaluations": k_a, "seconds": round(dt_a, 2)}
-    # (b) one fit per core; the 1-GPU box's CPU share is 16 processes
-    workers = int(max(1, min(ncpu, 16, Y.shape[0])))
+    # (b) one fit per PHYSICAL core of the affinity mask ("all physical cores ... one fit per core"),
+    # bounded by a cgroup CPU quota when the box has one; WV_CPU_WORKERS overrides
+    phys, quota = physical_cores()
+    workers = int(os.environ.get("WV_CPU_WORKERS", 0)) or int(max(1, min(phys, quota or phys, 128, Y.shape[0])))
     try:
-        k_b = int(max(1, min(6, half / max(2.0 * t_first, 1e-3))))
+        # with every core busy an evaluation is slower than the lone threaded one above (shared L3 / memory bandwidth):
+        # 2 - 3 evaluations per worker keep the pool inside its half of the budget
+        k_b = int(max(2, min(3, half / max(6.0 * t_first, 1e-3))))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(k_b),
@@ -132,7 +160,8 @@ def cpu_baseline_measure(X, Y, seconds_budget=24.0):
     theta0 = np.asarray(headline_spec().theta(), dtype=np.float64)
     check = {"oracle_port": float(gp_oracle.lml(spec, theta0, X, Y[0])),
              "closed_form": float(closed_forms.headline_closed_form(theta0, X, Y[0]))}
-    return {"ncpu": ncpu, "blas_threads": blas_threads, "workers": workers, "all_threads_one_fit": mode_a,
+    return {"ncpu": ncpu, "physical_cores": phys, "cgroup_cpu_quota": quota, "blas_threads": blas_threads,
+            "workers": workers, "all_threads_one_fit": mode_a,
             "one_fit_per_core": mode_b, "lml_check": check}
 
 
@@ -161,6 +190,7 @@ def cpu_baseline_finish(raw, evals_per_fit):
     return {"value": max(rate_a, rate_b), "unit": "fits/s",
             "cores": raw["workers"] if use_b else (raw["blas_threads"] or raw["ncpu"]), "kind": "port",
             "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": raw["ncpu"],
+            "physical_cores_in_affinity_mask": raw["physical_cores"], "cgroup_cpu_quota_cores": raw["cgroup_cpu_quota"],
             "evals_per_fit_used": evals_per_fit,
             "sample": f"extrapolated from {k} timed value+gradient evaluations per core of oracle/gp_oracle.py "
                       "(NumPy/SciPy: dpotrf + dpotri, term-by-term trace) on the headline workload (N=2048, same X and "
@@ -309,6 +339,97 @@ def bench_c2(args):
     print(json.dumps(out), flush=True)
 
 
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N ...` with no WORLD_SIZE in the environment: start the N rank processes ourselves
+    (what `python -m torch.distributed.run --nproc-per-node N` does for the driver - that path keeps working, it sets
+    WORLD_SIZE).  This parent never touches the GPU and never imports torch or the library: it picks a free rendezvous
+    port on 127.0.0.1, starts `bench.py <same arguments>` N times as CHILD processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (no exec), forwards rank 0's ONE JSON line to its own stdout (everything else the children write goes
+    to stderr) and returns the worst child exit code.  If a rank dies, the others - which would wait in a collective for
+    ever - are ended by PID after a grace period."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL across processes: dmabuf IPC only on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, ncpu // n)))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    import threading
+
+    lines = []
+
+    def read_rank0():
+        # rank 0's stdout carries exactly one line (main() parks fd 1 on stderr until the JSON is written)
+        for raw in procs[0].stdout:
+            txt = raw.decode(errors="replace").rstrip("\n")
+            if txt.startswith("{") and '"metric"' in txt:
+                lines.append(txt)
+            elif txt:
+                print(txt, file=sys.stderr)
+
+    reader = threading.Thread(target=read_rank0, daemon=True)
+    reader.start()
+    rcs = [None] * n
+    killed = set()
+    grace = float(os.environ.get("WV_LAUNCH_GRACE_S", "30"))
+    t_fail = None
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs) and t_fail is None:
+            t_fail = time.perf_counter()
+        if t_fail is not None and time.perf_counter() - t_fail > grace:
+            for i, pr in enumerate(procs):
+                if rcs[i] is None and i not in killed:
+                    killed.add(i)
+                    pr.kill()       # the exact PID we started
+        time.sleep(0.2)
+    reader.join(timeout=10.0)
+    line = lines[-1] if lines else None
+    # the worst exit code of the ranks that ended by themselves (a rank we had to end reports the failure that stranded it)
+    worst = max((abs(rc) for i, rc in enumerate(rcs) if i not in killed), default=0) or (1 if killed else 0)
+    if line is not None and worst == 0:
+        print(line, flush=True)
+    elif worst == 0:
+        print("bench.py: rank 0 exited 0 without a result line", file=sys.stderr)
+        worst = 1
+    else:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return min(worst, 255)
+
+
+def _launch_selftest(mode, rank, world):
+    """What a rank does under `--launch-selftest`: the rendezvous `launch_ranks` set up, for real, on the CPU."""
+    import torch
+    import torch.distributed as dist
+
+    if mode == "fail" and rank == world - 1:
+        sys.exit(3)
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print("a stray line a library might print", flush=True)
+        print(json.dumps({"metric": "launch-selftest", "world": dist.get_world_size(), "rank_sum": float(t.item()),
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "master_addr": os.environ.get("MASTER_ADDR")}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker_main(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
@@ -321,6 +442,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="fits in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed per-stage step")
+    ap.add_argument("--launch-selftest", default=None, choices=["ok", "fail"],
+                    help="CPU-only check of the self-launch path (tests/test_parallel.py): the ranks meet over gloo, "
+                         "all-reduce their ranks, rank 0 prints one line; 'fail' makes the last rank exit 3 instead")
     ap.add_argument("--config", default="headline", choices=["headline", "c2", "c5"],
                     help="headline: the BASELINE metric (default).  c2: BASELINE configs[1], one output, single-fit "
                          "latency.  c5: BASELINE configs[4], N=16384 float32 stress")
@@ -330,13 +454,17 @@ def main():
     if args.config == "c2":
         return bench_c2(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called like the N = 1 command (`python3 bench.py --gpus N ...`), without a launcher: be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-            sys.exit(2)
+    if args.launch_selftest:
+        return _launch_selftest(args.launch_selftest, rank, world)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with the launcher's {world} rank(s)",
+              file=sys.stderr)
 
     from waveome_amd import parallel
     from waveome_amd.engine import Context, Problem, lbfgs_opts

@@ -58,6 +58,18 @@ if rank == 0:
 # fewer chunks than ranks: a rank that draws nothing still joins the gather
 tiny = parallel.dynamic_map(1, parallel.pull_all(work), chunk=4, width=2)
 assert tiny.shape == (1, 2) and tiny[0, 0] == 0.5
+# the dealer's counter lives in a store this module made with public API only (a TCPStore on rank 0, the port broadcast
+# as a tensor) - never in torch's private rendezvous store - and it is made once per process group
+st1 = parallel.deal_store()
+assert st1 is parallel.deal_store() and type(st1).__name__ == "PrefixStore"
+import torch.distributed.distributed_c10d as c10d
+assert "_get_default_store" not in open(parallel.__file__).read().replace("`distributed_c10d._get_default_store`", "")
+# ... or in one the caller hands over: every rank passes a handle to the same store
+from torch.distributed import FileStore
+parallel.set_deal_store(FileStore(os.environ["WV_OUT"] + ".filestore", world))
+assert parallel.deal_store() is not st1
+dyn2 = parallel.dynamic_map(64, parallel.pull_all(lambda ids: np.column_stack([ids * 2.0 + 0.5, cost_ms[ids]])), chunk=3, width=2)
+assert np.array_equal(dyn2, dyn) and sum(parallel.last_map_stats()["tasks_per_rank"]) == 64
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -151,3 +163,38 @@ def test_task_dealer_and_dynamic_map_without_a_process_group():
 
     with pytest.raises(RuntimeError):   # a run() that loses tasks it drew is an error, not a silent NaN row
         parallel.dynamic_map(5, lambda dealer: (dealer.pull()[:1], np.zeros((1, 1))), chunk=3, width=1)
+
+
+def _bench(*args, env=None):
+    e = dict(os.environ, OMP_NUM_THREADS="1", **(env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, timeout=240)
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python3 bench.py --gpus N` without WORLD_SIZE used to print "launch with
+    torch.distributed.run" and exit 2.  Now the parent starts N rank children (itself, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set), forwards rank 0's one JSON line and returns the worst child exit code.  The selftest
+    ranks really meet over gloo on 127.0.0.1 and all-reduce their ranks; a stray stdout line of rank 0 goes to stderr."""
+    import json
+
+    r = _bench("--gpus", "3", "--launch-selftest", "ok")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE line on stdout
+    out = json.loads(lines[0])
+    assert out == {"metric": "launch-selftest", "world": 3, "rank_sum": 3.0, "local_rank_env": "0", "master_addr": "127.0.0.1"}
+    assert "a stray line" in r.stderr.decode()
+    # the parent must stay GPU-free: it never imports torch or the library
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def _launch_selftest")]
+    assert "import torch" not in body and "waveome_amd" not in body and "os.exec" not in body
+
+
+def test_bench_launcher_returns_a_failed_ranks_exit_code():
+    """A rank that dies strands the others in their rendezvous: the parent ends them by PID after the grace period and
+    reports the code of the rank that failed by itself; no result line."""
+    r = _bench("--gpus", "2", "--launch-selftest", "fail", env={"WV_LAUNCH_GRACE_S": "2"})
+    assert r.returncode == 3, (r.returncode, r.stderr.decode()[-2000:])
+    assert r.stdout.decode().strip() == ""

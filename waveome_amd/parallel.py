@@ -267,9 +267,57 @@ def sharded_map(n_tasks: int, fn: Callable[[np.ndarray], np.ndarray], costs=None
 # ---------------------------------------------------------------------------------------------------------------
 # dynamic dealing: chunks of the task list handed out on demand from a counter every rank can reach
 # ---------------------------------------------------------------------------------------------------------------
+_DEAL_STORE = None      # (store, id of the process group it was made for)
+
+
+def set_deal_store(store) -> None:
+    """Hand the dealer a key-value store every rank can reach (any `torch.distributed.Store`: the TCPStore / FileStore the
+    caller passed to `init_process_group(store=...)`, for instance).  Collective in spirit: every rank must pass a handle
+    to the SAME store.  Keys are kept under the prefix "waveome_amd/"."""
+    global _DEAL_STORE
+    from torch.distributed import PrefixStore
+
+    _DEAL_STORE = (PrefixStore("waveome_amd", store), _group_token())
+
+
+def _group_token():
+    dist = _dist()
+    return id(dist.group.WORLD) if dist.is_initialized() else None
+
+
+def deal_store():
+    """The key-value store behind `TaskDealer`'s shared counter.  The caller's (`set_deal_store`) when one was passed
+    for the current process group; otherwise one this module creates, once per process group and collectively: rank 0
+    opens a `TCPStore` on a free port of its own address (MASTER_ADDR, else 127.0.0.1), the port travels to the other
+    ranks as an int64 tensor on `collective_device()`, and they connect as clients.  Only public torch.distributed API:
+    the process group's own rendezvous store is private to torch (`distributed_c10d._get_default_store`) and is not
+    touched."""
+    global _DEAL_STORE
+    if _DEAL_STORE is not None and _DEAL_STORE[1] == _group_token():
+        return _DEAL_STORE[0]
+    import datetime
+    import os
+
+    import torch
+    from torch.distributed import PrefixStore, TCPStore
+
+    dist = _dist()
+    rank, world = dist_info()
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    timeout = datetime.timedelta(seconds=300)
+    server = None
+    if rank == 0:
+        server = TCPStore(host, 0, world, is_master=True, timeout=timeout, wait_for_workers=False)
+    port = torch.tensor([server.port if rank == 0 else 0], dtype=torch.int64, device=collective_device())
+    dist.broadcast(port, src=0)
+    store = server if rank == 0 else TCPStore(host, int(port.item()), world, is_master=False, timeout=timeout)
+    _DEAL_STORE = (PrefixStore("waveome_amd", store), _group_token())
+    return _DEAL_STORE[0]
+
+
 class TaskDealer:
-    """Hands out the task list in chunks, on demand.  Under torch.distributed the position lives in the process
-    group's key-value store (`store.add` is atomic: the TCPStore torchrun already set up, no extra service), so a rank
+    """Hands out the task list in chunks, on demand.  Under torch.distributed the position lives in a key-value store
+    every rank reaches (`deal_store()`: a TCPStore on rank 0, or the store the caller passed; `store.add` is atomic), so a rank
     that finishes early simply draws the next chunk - what Ray's scheduler did for the reference, one task at a time
     (waveome/model_search.py:474-489, 1200-1222).  The sequence is the same on every rank; without a process group
     the counter is local.  Creating a dealer is a collective: rank 0 claims the counter's key and broadcasts it.
@@ -300,16 +348,20 @@ class TaskDealer:
         self._store = None
         self._key = None
         if dist_active():
-            from torch.distributed import distributed_c10d
-
             # The counter's key has to be the SAME on every rank.  A per-process sequence number is not: a dealer created
             # on some ranks only (an exception, a retry) would shift it silently and every rank would then deal itself the
             # whole list.  Rank 0 claims a number from the store and broadcasts it - creating a dealer is a collective
-            # (all callers are), and a rank that creates one alone fails loudly in the broadcast instead.
-            self._store = distributed_c10d._get_default_store()
-            box = [int(self._store.add("waveome_amd/deal/next", 1)) if dist_info()[0] == 0 else None]
-            _dist().broadcast_object_list(box, src=0)
-            self._key = f"waveome_amd/deal/{box[0]}"
+            # (all callers are), and a rank that creates one alone fails loudly in the broadcast instead.  The number
+            # travels as an int64 TENSOR on `collective_device()` like every other collective of this module: an object
+            # broadcast would stage on torch.cuda.current_device() under nccl, which is cuda:0 on every rank of a caller
+            # that never called torch.cuda.set_device.
+            import torch
+
+            self._store = deal_store()
+            n = int(self._store.add("deal/next", 1)) if dist_info()[0] == 0 else 0
+            t = torch.tensor([n], dtype=torch.int64, device=collective_device())
+            _dist().broadcast(t, src=0)
+            self._key = f"deal/{int(t.item())}"
 
     def pull(self) -> np.ndarray:
         """The next piece of task indices (empty once the list is exhausted)."""
