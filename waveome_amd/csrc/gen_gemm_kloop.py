@@ -73,7 +73,19 @@ def acc(i, j, r):
 
 
 # assembler-time lookup of the four accumulator operands' base registers (no instructions)
-ACC_PRELUDE = [f".ifc %[c{k}],a[{b}:{b + 31}]\\n\\t.set WVACC{k},{b}\\n\\t.endif" for k in range(4) for b in range(0, 97)]
+def _prelude(sym, file, width, last):
+    """Per operand k: reset the symbol (assembler symbols are global to the whole .s file - without the reset an operand
+    that prints in an unforeseen way would silently keep the previous statement's value), the .ifc chain, and an
+    assembler error when nothing matched."""
+    out = []
+    for k in range(4):
+        out.append(f".set {sym}{k},-1")
+        out += [f".ifc %[c{k}],{file}[{b}:{b + width - 1}]\\n\\t.set {sym}{k},{b}\\n\\t.endif" for b in range(0, last + 1)]
+        out.append(f".if {sym}{k}<0\\n\\t.error \\\"gen_gemm_kloop: accumulator operand c{k} is not a {file}[b:b+{width - 1}] tuple\\\"\\n\\t.endif")
+    return out
+
+
+ACC_PRELUDE = _prelude("WVACC", "a", 32, 96)
 
 
 def va(buf, i):
@@ -382,7 +394,7 @@ class SmallRegs:
         return f"v[WVC{i}+{2 * r}:WVC{i}+{2 * r + 1}]"
 
 
-SMALL_PRELUDE = [f".ifc %[c{k}],v[{b}:{b + 7}]\\n\\t.set WVC{k},{b}\\n\\t.endif" for k in range(4) for b in range(0, 249)]
+SMALL_PRELUDE = _prelude("WVC", "v", 8, 248)
 S_DB = 90   # B's stage toggle (the two operands' stages differ in size when A is K-contiguous)
 
 

@@ -1111,8 +1111,11 @@ static double kernel_diag_at(const Spec& s, const double* theta, const double* x
 // The float64, complete-case twin that serves the post-fit calls of a float32 problem or of one with missing outputs
 // (Problem::twin).  One column at a time: without missing values a change of column is one device copy of Y's column;
 // with them the observed rows differ from column to column and the twin is rebuilt (7 ms at N = 2048; these calls are
-// one evaluation each, after the fits).
-static int32_t post_fit_twin(Problem& p, int col, const char* who) {
+// one evaluation each, after the fits) from the host copies of X and the masks kept beside it.
+// `want_slots`: batch slots the caller can use - 1 for wv_predict / wv_whitened_state; wv_whitened_means factors its
+// leave-one-out Gram matrices as a batch (up to 8, within 8 GiB).  The twin is created with what the first caller needs
+// and re-created larger only when a later call asks for more: a predict alone pins 4 N^2 doubles, not 32 N^2.
+static int32_t post_fit_twin(Problem& p, int col, const char* who, int want_slots) {
   if (p.specs.size() != 1) {
     set_error(std::string(who) + ": the problem holds several structures (only wv_fit_multi serves those)");
     return WV_E_UNSUPPORTED;
@@ -1122,8 +1125,11 @@ static int32_t post_fit_twin(Problem& p, int col, const char* who) {
     return WV_E_BADARG;
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));
-  if (p.twin && p.twin_col == col) return WV_OK;
-  if (p.twin && !p.dmask) {
+  const int64_t per_slot = 4 * (int64_t)sizeof(double) * p.Npad * p.Npad;
+  const int slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(8, std::max(1, want_slots)), ((int64_t)8 << 30) / per_slot));
+  const bool big_enough = p.twin && p.twin_slots >= slots;
+  if (big_enough && p.twin_col == col) return WV_OK;
+  if (big_enough && !p.dmask) {
     WV_HIP_TRY(hipMemcpy(p.twin->p.dY, p.dY + (int64_t)col * p.Npad, sizeof(double) * p.Npad, hipMemcpyDeviceToDevice));
     p.twin_col = col;
     return WV_OK;
@@ -1132,26 +1138,27 @@ static int32_t post_fit_twin(Problem& p, int col, const char* who) {
     wv_problem_destroy(p.twin);
     p.twin = nullptr;
     p.twin_col = -1;
+    p.twin_slots = 0;
   }
   p.ctx64 = *p.ctx;
   p.ctx64.dtype = 0;
-  // batch slots: wv_whitened_means factors its leave-one-out Gram matrices as a batch - up to 8, within 8 GiB
-  const int64_t per_slot = 4 * (int64_t)sizeof(double) * p.Npad * p.Npad;
-  const int slots = (int)std::max<int64_t>(1, std::min<int64_t>(8, ((int64_t)8 << 30) / per_slot));
   int32_t rc;
   p.twin_rows.clear();
   if (!p.dmask) {
     rc = create_from_specs(&p.ctx64, p.dX, p.N, p.D, p.dY + (int64_t)col * p.Npad, 1, {p.spec}, nullptr, slots, 1, 1, &p.twin);
   } else {
+    if (p.twin_hostX.empty()) {   // X does not change over the life of a problem: one download
+      p.twin_hostX.resize((size_t)p.N * p.D);
+      WV_HIP_TRY(hipMemcpy(p.twin_hostX.data(), p.dX, sizeof(double) * p.N * p.D, hipMemcpyDeviceToHost));
+    }
     std::vector<uint8_t> mask(p.N);
     std::vector<double> X((size_t)p.N * p.D), y(p.N);
     WV_HIP_TRY(hipMemcpy(mask.data(), p.dmask + (int64_t)col * p.Npad, p.N, hipMemcpyDeviceToHost));
-    WV_HIP_TRY(hipMemcpy(X.data(), p.dX, sizeof(double) * p.N * p.D, hipMemcpyDeviceToHost));
     WV_HIP_TRY(hipMemcpy(y.data(), p.dY + (int64_t)col * p.Npad, sizeof(double) * p.N, hipMemcpyDeviceToHost));
     int64_t n = 0;
     for (int64_t i = 0; i < p.N; ++i)
       if (mask[i]) {
-        if (n != i) std::copy(X.begin() + i * p.D, X.begin() + (i + 1) * p.D, X.begin() + n * p.D);
+        std::copy(p.twin_hostX.begin() + i * p.D, p.twin_hostX.begin() + (i + 1) * p.D, X.begin() + n * p.D);
         y[n++] = y[i];
         p.twin_rows.push_back(i);
       }
@@ -1164,6 +1171,7 @@ static int32_t post_fit_twin(Problem& p, int col, const char* who) {
     return rc;
   }
   p.twin_col = col;
+  p.twin_slots = slots;
   return WV_OK;
 }
 
@@ -1177,7 +1185,7 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
   if (p.f32 || p.dmask) {
     // float64 on the complete cases of this column (Problem::twin).  Training inputs of a problem with missing outputs:
     // all N rows - the observed ones by the training-input identities, the others as new inputs.
-    if (int rc = post_fit_twin(p, col, "wv_predict")) return rc;
+    if (int rc = post_fit_twin(p, col, "wv_predict", 1)) return rc;
     if (Xnew || p.twin_rows.empty()) return wv_predict(p.twin, 0, theta, Xnew, M, include_noise, mean_out, var_out);
     const int64_t n = (int64_t)p.twin_rows.size(), nmiss = p.N - n;
     std::vector<double> m(std::max(n, nmiss)), v(std::max(n, nmiss));
@@ -1190,8 +1198,8 @@ int32_t wv_predict(wv_problem* h, int32_t col, const double* theta, const double
       if (mean_out) mean_out[i] = m[k];
       if (var_out) var_out[i] = v[k];
     }
-    std::vector<double> Xall((size_t)p.N * p.D), Xm((size_t)nmiss * p.D);
-    WV_HIP_TRY(hipMemcpy(Xall.data(), p.dX, sizeof(double) * p.N * p.D, hipMemcpyDeviceToHost));
+    const std::vector<double>& Xall = p.twin_hostX;   // (kept by post_fit_twin: no second download)
+    std::vector<double> Xm((size_t)nmiss * p.D);
     std::vector<int64_t> miss;
     for (int64_t i = 0; i < p.N; ++i)
       if (!seen[i]) {
@@ -1315,7 +1323,7 @@ int32_t wv_whitened_means(wv_problem* h, int32_t col, const double* theta, const
   Problem& p = h->p;
   if (p.f32 || p.dmask) {
     // float64 on the complete cases of this column (Problem::twin); rows missing for this column answer NaN
-    if (int rc = post_fit_twin(p, col, "wv_whitened_means")) return rc;
+    if (int rc = post_fit_twin(p, col, "wv_whitened_means", n_masks)) return rc;
     if (p.twin_rows.empty()) return wv_whitened_means(p.twin, 0, theta, term_masks, n_masks, jitter, means_out);
     const int64_t n = (int64_t)p.twin_rows.size();
     std::vector<double> mm((size_t)n_masks * n);
@@ -1416,7 +1424,7 @@ int32_t wv_whitened_state(wv_problem* h, int32_t col, const double* theta, doubl
     return WV_E_UNSUPPORTED;
   }
   if (p.f32) {  // float64 on a twin of this problem (Problem::twin)
-    if (int rc = post_fit_twin(p, col, "wv_whitened_state")) return rc;
+    if (int rc = post_fit_twin(p, col, "wv_whitened_state", 1)) return rc;
     return wv_whitened_state(p.twin, 0, theta, jitter, q_mu_out, q_sqrt_out);
   }
   WV_HIP_TRY(hipSetDevice(p.ctx->device));

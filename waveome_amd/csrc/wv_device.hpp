@@ -211,7 +211,9 @@ struct Problem {
   Ctx ctx64;
   ::wv_problem* twin = nullptr;
   int twin_col = -1;
+  int twin_slots = 0;                 // batch slots the twin was created with (grown when wv_whitened_means asks for more)
   std::vector<int64_t> twin_rows;
+  std::vector<double> twin_hostX;     // host copy of X (missing-output problems: the twin is re-made per column)
   int64_t pbuf_elems() const { int64_t h = Npad / 2 + NB; return std::max<int64_t>(h * h, Npad * NB); }
   int nblk() const { return (int)(Npad / NB); }
   int ntiles() const { int t = (int)(Npad / GT); return t * (t + 1) / 2; }
