@@ -137,7 +137,7 @@ def cpu_baseline_measure(X, Y, seconds_budget=24.0):
     try:
         # with every core busy an evaluation is slower than the lone threaded one above (shared L3 / memory bandwidth):
         # 2 - 3 evaluations per worker keep the pool inside its half of the budget
-        k_b = int(max(2, min(3, half / max(6.0 * t_first, 1e-3))))
+        k_b = 2 if workers > 32 else int(max(2, min(6, half / max(2.0 * t_first, 1e-3))))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(k_b),
@@ -195,7 +195,9 @@ def cpu_baseline_finish(raw, evals_per_fit):
             "sample": f"extrapolated from {k} timed value+gradient evaluations per core of oracle/gp_oracle.py "
                       "(NumPy/SciPy: dpotrf + dpotri, term-by-term trace) on the headline workload (N=2048, same X and "
                       "Y columns), timed before the GPU run; fits/s = evaluations/s / the evaluations per 100-iteration "
-                      "fit measured on the timed GPU fits; value = better of the two modes",
+                      "fit measured on the timed GPU fits; value = better of the two modes; the one-fit-per-core pool "
+                      "has one single-threaded worker per physical core of the affinity mask, capped by the cgroup CPU "
+                      "quota of the box (cpu.max) when there is one - more workers than the quota only time-slice",
             "all_threads_one_fit": a, "one_fit_per_core": b}
 
 
