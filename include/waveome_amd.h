@@ -174,8 +174,10 @@ int32_t wv_device_count(int32_t* count_out);
 /* One context per GPU, process and precision.  dtype: 0 = float64; 1 = float32 storage and MFMA products
  * for the N x N work matrices of problems created on this context - the reference's
  * set_precision("float32") (waveome/utilities.py:34-49).  Parameters, X, Y, vectors, reductions and
- * every number crossing this ABI stay float64.  wv_predict / wv_whitened_means are float64-only
- * (WV_E_UNSUPPORTED on a float32 problem). */
+ * every number crossing this ABI stay float64.  The float32 products accumulate through float64 sums and every value
+ * (wv_lml, wv_value_grad, the fits) is corrected back to float64 through E = M K_y M' - I with K_y recomputed in
+ * float64 (wv_chol.hip, reduce_kernel): 1e-7 relative to the float64 path at N = 16384 for cond(K_y) ~ 5e4; wv_lml
+ * therefore costs a gradient evaluation on such a context.  Post-fit calls run on a float64 twin of the problem. */
 int32_t wv_ctx_create(int32_t device_ordinal, int32_t dtype, wv_ctx** out);
 void wv_ctx_destroy(wv_ctx* ctx);
 /* Block until all work queued on this context's GPU has finished (hipDeviceSynchronize). */

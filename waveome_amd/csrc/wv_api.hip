@@ -28,6 +28,7 @@ static const char* const kTuningSwitches[] = {
     "WV_BLOCKS",         // 0: no zero-block skipping (dense products on block-diagonal structures)
     "WV_VALUE_FULL",     // value-only evaluations through factor + inverse (same LML to rounding, not to the bit)
     "WV_FIT_TRACE",      // host-side timing of a fit loop on stderr (no effect on results)
+    "WV_F32_ORDER",      // float32 contexts: order of the value correction in E = Mt K_y Mt' - I (1 default; 2, 4: + probe passes)
 };
 const char* tuning_env(const char* name) {
   for (const char* s : kTuningSwitches)
@@ -172,6 +173,9 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
   launch_gram(p, st, g.slot0, nb, 0);
   static const bool old_sched = experiment_env("WV_SCHED_OLD") != nullptr;  // (round 1's right-looking schedule)
   static const bool full_value = tuning_env("WV_VALUE_FULL") != nullptr;   // value-only through factor + inverse
+  // float32 contexts: the value is only a float64-grade number with the first-order correction that the gradient
+  // pipeline's trace pass accumulates (reduce_kernel), so value-only evaluations run that pipeline too
+  if (p.f32) with_grad = true;
   if (old_sched) {
     cholesky(p, st, g.slot0, nb);
     trtri(p, st, g.slot0, nb);
@@ -184,6 +188,7 @@ static int enqueue_eval(Problem& p, Group& g, int nb, bool with_grad) {
   }
   if (with_grad) {
     lauum(p, st, g.slot0, nb);
+    if (p.f32) launch_f32_refine(p, st, g.slot0, nb);   // (before the trace pass: it reads the float64 diagonal of Mt'Mt)
     launch_trace(p, st, g.slot0, nb);
   }
   launch_reduce(p, st, g.slot0, nb, with_grad);
@@ -334,7 +339,7 @@ void wv_problem_destroy(wv_problem* h) {
   void* ptrs[] = {p.dX, p.dY, p.dspec, p.Kbuf, p.Mbuf, p.MTbuf, p.Pbuf, p.dtheta, p.dr, p.dz, p.dalpha, p.dfeat, p.dfconst,
                   p.dlogdet, p.dpart, p.dout, p.dcol, p.dstatus, p.dsolve_part, p.dslotspec, p.dspans, p.dspec_span, p.dmask,
                   p.dnobs, p.Kbuf32, p.Mbuf32, p.MTbuf32,
-                  p.Pbuf32, p.dquad};
+                  p.Pbuf32, p.dquad, p.df32r};
   for (void* q : ptrs)
     if (q) hipFree(q);
   delete h;
@@ -436,6 +441,7 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
     p.any_product |= hspecs[si].n_factors > hspecs[si].n_terms;
   }
   p.spec_cap = n_specs;
+  const int ksum = p.f32 ? 1 : 0;   // float32 contexts: one more sum slot and record column in the trace pass (KSUM)
   if (caps) {  // room for structures added later (wv_problem_add_spec)
     if (caps->max_feat > MAX_FEAT || caps->max_factors > 128 || caps->max_specs > (1 << 20)) {
       set_error("wv_problem_create_ex: capacity beyond the device limits (64 features, 128 factors)");
@@ -448,6 +454,7 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
     p.max_red = std::max(p.max_red, (int)caps->max_red);
     if (caps->max_specs > n_specs) p.any_multidim = p.any_product = true;  // (later structures may act on several columns or carry products: the general kernels)
   }
+  p.max_red += ksum;
   p.specs.reserve(p.spec_cap);
   for (auto& d : hspecs) d.n_params = p.np_stride;  // the device uses this field as the table stride
   p.spec = p.specs[0];
@@ -490,11 +497,12 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
             alloc((void**)&p.dfeat, sizeof(double) * 2 * std::max(1, p.max_feat) * Np * max_batch) &&
             alloc((void**)&p.dfconst, sizeof(double) * 4 * std::max(1, p.max_fact) * max_batch) &&
             alloc((void**)&p.dlogdet, sizeof(double) * p.nblk() * max_batch) &&
-            alloc((void**)&p.dpart, sizeof(double) * trace_part_stride(p) * np * max_batch) &&
+            alloc((void**)&p.dpart, sizeof(double) * trace_part_stride(p) * (np + ksum) * max_batch) &&
             alloc((void**)&p.dout, sizeof(double) * p.out_stride * max_batch) &&
             alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
             alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
   if (ok && Np <= 2048 && !p.f32) ok = alloc((void**)&p.dsolve_part, sizeof(double) * (Np / 64) * Np * max_batch);
+  if (ok && p.f32) ok = alloc((void**)&p.df32r, sizeof(double) * F32R_VECS * Np * max_batch);
   if (!ok) {
     set_error("device allocation failed (workspace for max_batch fits does not fit in HBM)");
     return WV_E_OOM;
@@ -513,7 +521,19 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
     WV_HIP_TRY(hipMemset(p.MTbuf, 0, sizeof(double) * mat * max_batch));
   }
   WV_HIP_TRY(hipMemset(p.dalpha, 0, sizeof(double) * Np * max_batch));
-  WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * np * max_batch));
+  WV_HIP_TRY(hipMemset(p.dpart, 0, sizeof(double) * nwg * (np + ksum) * max_batch));
+  if (p.f32) {
+    // the probe vector of the second-order term (Rademacher, fixed: the objective stays a deterministic function)
+    std::vector<double> hv((size_t)F32R_VECS * Np * max_batch, 0.0);
+    uint64_t sd = 0x9E3779B97F4A7C15ull;
+    std::vector<double> v(Np);
+    for (int64_t i = 0; i < Np; ++i) {
+      sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17;
+      v[i] = (sd >> 33) & 1 ? 1.0 : -1.0;
+    }
+    for (int b = 0; b < max_batch; ++b) std::copy(v.begin(), v.end(), hv.begin() + ((size_t)b * F32R_VECS + F32R_V) * Np);
+    WV_HIP_TRY(hipMemcpy(p.df32r, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
+  }
   WV_HIP_TRY(hipMemcpy(p.dX, X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   bool y_uploaded = false;
   if (caps && caps->nan_is_missing) {
@@ -1510,7 +1530,7 @@ int32_t wv_problem_add_spec(wv_problem* h, const wv_kernel_spec* spec, int32_t* 
     set_error(e);
     return WV_E_UNSUPPORTED;
   }
-  if (sp.n_params() > p.np_stride || d.n_feat > p.max_feat || d.n_factors > p.max_fact || d.n_red > p.max_red) {
+  if (sp.n_params() > p.np_stride || d.n_feat > p.max_feat || d.n_factors > p.max_fact || d.n_red + (p.f32 ? 1 : 0) > p.max_red) {
     set_error("wv_problem_add_spec: the structure exceeds a capacity the problem was created with");
     return WV_E_UNSUPPORTED;
   }

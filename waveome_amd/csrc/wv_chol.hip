@@ -776,6 +776,115 @@ void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha
 }
 
 // ---------------------------------------------------------------------------------------
+// float32 contexts: what turns the float32 factor's value into a float64-grade number.
+// With Mt = the STORED float32 inverse factor and E = Mt K_y Mt' - I (K_y in float64, recomputed - never stored):
+//   log|K_y| = -2 sum log Mt_ii + tr E - 1/2 tr E^2 + ...      r'K_y^-1 r = zt'zt - zt'E zt + zt'E^2 zt - ...,  zt = Mt r
+// First order (tr E, zt'E zt) comes from the trace pass (KSUM: sum W K_y); here: the float64 diagonal of Mt'Mt that pass
+// uses, and the second-order terms -  zt'E^2 zt = |E zt|^2 exactly, E zt = Mt (K_y alpha) - zt, and tr E^2 = |E|_F^2 by ONE
+// Rademacher probe v: |E v|^2, E v = Mt (K_y (Mt' v)) - v.  E of a float32 factor is a dense matrix of rounding errors
+// (participation ratio ~1e3 measured, tools/probe_f32_residual.py): a single probe gives |E|_F^2 to 1 - 4 %, of a term that
+// is itself ~2e-5 of the LML at N = 16384.  O(N^2) work: three passes over Mt, one Gram recomputation.
+// ---------------------------------------------------------------------------------------
+// WV_F32_ORDER (release switch, wv_api.hip): 1 (default) = the first-order correction only - all a float32 factor with
+// float64-flushed accumulators needs at the sizes measured (8e-8 relative at N = 16384); 2 = + second order, 4 = + third and
+// fourth (one more application of E): for ill-conditioned K_y (cond * 6e-8 no longer small).
+int f32_order() {
+  static const int order = [] { const char* e = tuning_env("WV_F32_ORDER"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+  return order;
+}
+
+// TWO right-hand sides per pass over the stored factor (vectors live in the [F32R_VECS][Npad] block of a slot, or - the
+// `ext` ones: alpha, zt - in arrays of stride Npad):
+//   TRANS:  out1 = M' in1, out2 = M' in2, and (pd != null) pd = diag(M'M) = the columns' sums of squares, in float64
+//   else :  out1 = M in1 - sub1, out2 = M in2 - sub2
+template <typename R, bool TRANS>
+__global__ __launch_bounds__(256) void trmv2_kernel(const R* __restrict__ Mall, const double* __restrict__ in1_all,
+                                                    const double* __restrict__ in2_all, int64_t in_stride,
+                                                    const double* __restrict__ sub1_all, int64_t sub1_stride,
+                                                    const double* __restrict__ sub2_all, int64_t sub2_stride,
+                                                    double* __restrict__ out1_all, double* __restrict__ out2_all,
+                                                    int64_t out_stride, double* __restrict__ pd_all, int64_t Npad, int slot0) {
+  __shared__ double red[3][4][64];
+  const int b = slot0 + blockIdx.y;
+  const R* M = Mall + (int64_t)b * Npad * Npad;
+  const double* x1 = in1_all + (int64_t)b * in_stride;
+  const double* x2 = in2_all ? in2_all + (int64_t)b * in_stride : nullptr;
+  double* y1 = out1_all + (int64_t)b * out_stride;
+  double* y2 = out2_all ? out2_all + (int64_t)b * out_stride : nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (TRANS) {   // 64 columns per workgroup, the waves stride over the rows (rows above the diagonal hold zeros)
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    double s1 = 0.0, s2 = 0.0, sq = 0.0;
+#pragma unroll 8
+    for (int64_t i = j0 + wave; i < Npad; i += 4) {
+      const double m = (double)M[i * Npad + j0 + lane];
+      s1 = fma(m, x1[i], s1);
+      if (x2) s2 = fma(m, x2[i], s2);
+      sq = fma(m, m, sq);
+    }
+    red[0][wave][lane] = s1; red[1][wave][lane] = s2; red[2][wave][lane] = sq;
+    __syncthreads();
+    if (wave == 0) {
+      y1[j0 + lane] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+      if (y2) y2[j0 + lane] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+      if (pd_all) pd_all[(int64_t)b * out_stride + j0 + lane] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
+    }
+  } else {       // 64 rows per workgroup: a wave takes 16 of them, four at a time (independent loads in flight)
+    const double* u1 = sub1_all + (int64_t)b * sub1_stride;
+    const double* u2 = sub2_all + (int64_t)b * sub2_stride;
+    for (int rr = 0; rr < 16; rr += 4) {
+      const int64_t i0 = (int64_t)blockIdx.x * 64 + wave * 16 + rr;
+      double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+      for (int64_t j = lane; j <= i0 + 3; j += 64) {
+        const double a1 = x1[j], a2 = x2[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double m = j <= i0 + q ? (double)M[(i0 + q) * Npad + j] : 0.0;
+          s1[q] = fma(m, a1, s1[q]);
+          s2[q] = fma(m, a2, s2[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+        if (lane == 0) { y1[i0 + q] = s1[q] - u1[i0 + q]; y2[i0 + q] = s2[q] - u2[i0 + q]; }
+      }
+    }
+  }
+}
+
+void launch_f32_refine(Problem& p, hipStream_t st, int slot0, int nb) {
+  const int order = f32_order();
+  if (!p.f32 || !p.df32r || order < 2) return;
+  const int64_t Np = p.Npad, vs = (int64_t)F32R_VECS * Np;
+  double* f = p.df32r;
+  auto vec = [&](int k) { return f + (int64_t)k * Np; };
+  const dim3 grid((unsigned)(Np / 64), nb), blk(256);
+  p.timer.begin(st, ST_SOLVE);   // w = Mt'v, diag(Mt'Mt)
+  hipLaunchKernelGGL((trmv2_kernel<float, true>), grid, blk, 0, st, p.Mbuf32, vec(F32R_V), nullptr, vs, nullptr, 0, nullptr, 0,
+                     vec(F32R_W), nullptr, vs, vec(F32R_PD), Np, slot0);
+  p.timer.end(st);
+  p.timer.begin(st, ST_GRAM);    // K_y [w, alpha]
+  launch_gram_matvec2(p, st, slot0, nb, vec(F32R_W), p.dalpha, vec(F32R_YV), vec(F32R_YA), vs, Np);
+  p.timer.end(st);
+  p.timer.begin(st, ST_SOLVE);   // E v = Mt K_y Mt'v - v,  E zt = Mt K_y alpha - zt;  then Mt' of both
+  hipLaunchKernelGGL((trmv2_kernel<float, false>), grid, blk, 0, st, p.Mbuf32, vec(F32R_YV), vec(F32R_YA), vs, vec(F32R_V), vs,
+                     p.dz, Np, vec(F32R_EV), vec(F32R_EA), vs, nullptr, Np, slot0);
+  if (order < 3) { p.timer.end(st); return; }
+  hipLaunchKernelGGL((trmv2_kernel<float, true>), grid, blk, 0, st, p.Mbuf32, vec(F32R_EV), vec(F32R_EA), vs, nullptr, 0, nullptr,
+                     0, vec(F32R_W2V), vec(F32R_W2A), vs, nullptr, Np, slot0);
+  p.timer.end(st);
+  p.timer.begin(st, ST_GRAM);
+  launch_gram_matvec2(p, st, slot0, nb, vec(F32R_W2V), vec(F32R_W2A), vec(F32R_Y2V), vec(F32R_Y2A), vs, vs);
+  p.timer.end(st);
+  p.timer.begin(st, ST_SOLVE);   // E^2 v, E^2 zt
+  hipLaunchKernelGGL((trmv2_kernel<float, false>), grid, blk, 0, st, p.Mbuf32, vec(F32R_Y2V), vec(F32R_Y2A), vs, vec(F32R_EV), vs,
+                     vec(F32R_EA), vs, vec(F32R_E2V), vec(F32R_E2A), vs, nullptr, Np, slot0);
+  p.timer.end(st);
+}
+
+// ---------------------------------------------------------------------------------------
 // reduce: out[b] = {lml, quad, logdet, dLML/dtheta[0..np)}
 // ---------------------------------------------------------------------------------------
 __device__ inline double block_sum(double v, double* sh) {
@@ -797,16 +906,39 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
                                                      int64_t Npad, int nblk, int nwg, int part_stride,
                                                      int out_stride, int slot0, int with_grad,
                                                      const int32_t* __restrict__ col,
-                                                     const int32_t* __restrict__ nobs) {
+                                                     const int32_t* __restrict__ nobs,
+                                                     const float* __restrict__ M32, const double* __restrict__ f32r,
+                                                     int high_orders) {
   __shared__ double sh[4];
   const int b = slot0 + blockIdx.x, tid = threadIdx.x;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const int np = sp->n_params;
-  double q = 0.0, sa = 0.0, ld = 0.0;
+  // M32 (float32 contexts, gradient evaluations): the trace pass's records carry one more column, sum w W K_y (KSUM)
+  const int ksum = (M32 && with_grad) ? 1 : 0;
+  double q = 0.0, sa = 0.0, ld = 0.0, slm = 0.0, swk = 0.0, te2 = 0.0, ze2 = 0.0, te3 = 0.0, ze3 = 0.0, te4 = 0.0, ze4 = 0.0;
   for (int64_t i = tid; i < Npad; i += 256) {
     double zz = zall[(int64_t)b * Npad + i];
     q += zz * zz;
     if (with_grad) sa += aall[(int64_t)b * Npad + i];
+    if (ksum) slm += log((double)M32[(int64_t)b * Npad * Npad + i * Npad + i]);   // the STORED inverse factor's diagonal
+    if (ksum && f32r) {   // (WV_F32_ORDER >= 2: launch_f32_refine ran)
+      const double* v = f32r + (int64_t)b * F32R_VECS * Npad;
+      const double ev = v[F32R_EV * Npad + i], ez = v[F32R_EA * Npad + i];      // (E v)_i, (E zt)_i
+      te2 = fma(ev, ev, te2);
+      ze2 = fma(ez, ez, ze2);
+      if (high_orders) {
+        const double e2v = v[F32R_E2V * Npad + i], e2z = v[F32R_E2A * Npad + i];  // (E^2 v)_i, (E^2 zt)_i
+        te3 = fma(ev, e2v, te3); te4 = fma(e2v, e2v, te4);
+        ze3 = fma(ez, e2z, ze3); ze4 = fma(e2z, e2z, ze4);
+      }
+    }
+  }
+  if (ksum) {
+    for (int w = tid; w < nwg; w += 256) swk += part[((int64_t)b * part_stride + w) * (np + 1) + np];
+    slm = block_sum(slm, sh);
+    swk = block_sum(swk, sh);
+    te2 = block_sum(te2, sh); te3 = block_sum(te3, sh); te4 = block_sum(te4, sh);
+    ze2 = block_sum(ze2, sh); ze3 = block_sum(ze3, sh); ze4 = block_sum(ze4, sh);
   }
   for (int i = tid; i < nblk; i += 256) ld += logdet[(int64_t)b * nblk + i];
   q = block_sum(q, sh);
@@ -818,6 +950,20 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
     o[0] = -0.5 * q - ld - 0.5 * n_seen * 1.8378770664093453;  // log(2 pi)
     o[1] = q;
     o[2] = ld;
+    if (ksum) {
+      // float32 context: Mt = the stored float32 inverse factor, zt = Mt r, at = Mt' zt, Wt = at at' - (Mt' Mt as the
+      // float32 product left it).  With E = Mt K_y Mt' - I:  K_y^-1 = Mt' (I + E)^-1 Mt  and  log|K_y| = -2 log|Mt| +
+      // log|I + E| EXACTLY (K_y in float64: the trace pass recomputes it); to first order in E
+      //   r' K_y^-1 r = 2 zt'zt - at' K_y at,    log|K_y| = -2 sum log Mt_ii + tr(Mt' Mt K_y) - n
+      // whose sum needs only sum_ij Wt_ij K_y,ij = 2 swk.  What is left is second order in E (~1e-9 relative at N = 16384)
+      // plus the rounding of the float32 product Mt' Mt inside Wt.
+      // ... orders two to four (launch_f32_refine): -1/2 log|I + E| -> + tr E^2 / 4 - tr E^3 / 6 + tr E^4 / 8 by the probe,
+      // -1/2 zt'(I + E)^-1 zt -> - zt'E^2 zt / 2 + zt'E^3 zt / 2 - zt'E^4 zt / 2 exactly
+      o[0] = -q + swk + slm + 0.5 * n_seen - 0.5 * n_seen * 1.8378770664093453
+             + 0.25 * te2 - te3 / 6.0 + 0.125 * te4 - 0.5 * ze2 + 0.5 * ze3 - 0.5 * ze4;
+      o[1] = te2;   // (diagnostics: |E v|^2 ~ |E|_F^2 and |E zt|^2)
+      o[2] = ze2;
+    }
   }
   if (with_grad) {
     // gradient = sum of the trace pass's per-workgroup partial sums: 16 parameters at a time, 16 threads per
@@ -829,7 +975,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const DevSpec* __restrict__
       const int p = p0 + pl;
       double g = 0.0;
       if (p < np)
-        for (int w = wl; w < nwg; w += 16) g += part[((int64_t)b * part_stride + w) * np + p];
+        for (int w = wl; w < nwg; w += 16) g += part[((int64_t)b * part_stride + w) * (np + ksum) + p];
       gsh[wl][pl] = g;
       __syncthreads();
       if (tid < 16 && p0 + tid < np) {
@@ -847,7 +993,8 @@ void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad
   p.timer.begin(st, ST_REDUCE);
   hipLaunchKernelGGL(reduce_kernel, dim3(nb), dim3(256), 0, st, p.dspec, p.dslotspec, p.dz, p.dalpha, p.dlogdet,
                      p.dpart, p.dout, p.N, p.Npad, p.nblk(), trace_nwg(p, nb), trace_part_stride(p), p.out_stride, slot0,
-                     with_grad ? 1 : 0, p.dcol, p.dmask ? p.dnobs : nullptr);
+                     with_grad ? 1 : 0, p.dcol, p.dmask ? p.dnobs : nullptr, p.f32 ? p.Mbuf32 : nullptr,
+                     f32_order() >= 2 ? p.df32r : nullptr, f32_order() >= 3 ? 1 : 0);
   p.timer.end(st);
 }
 

@@ -191,6 +191,10 @@ struct Problem {
   bool any_product = false;       // some structure has a product term (or may get one: capacity for later structures)
   int spec_cap = 0;               // entries of the device structure table (>= specs.size(): wv_problem_add_spec)
   double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
+  // float32 contexts only (the float64-grade value of a float32 evaluation, wv_chol.hip launch_f32_refine):
+  // [max_batch][F32R_VECS][Npad]: probe v, Mt'v, K_y Mt'v, K_y alpha, E v, E zt, Mt'E v, Mt'E zt, K_y Mt'E v, K_y Mt'E zt,
+  // E^2 v, E^2 zt, diag(Mt'Mt) in float64
+  double *df32r = nullptr;
   double *dlogdet = nullptr;   // [max_batch][nblk] partial log-determinants
   double *dpart = nullptr;     // [max_batch][ntiles][n_params] trace partials
   // few fits in flight (<= FEW_FITS): per-quad gradient accumulators of every tile, [groups][quad_fits][ntiles][quad_stride],
@@ -221,6 +225,8 @@ struct Problem {
 
 // result record layout per slot: [0]=lml, [1]=quad(z'z), [2]=logdet, [3..3+n_params)=dLML/dtheta
 inline int out_stride_for(int n_params) { return 3 + n_params; }
+constexpr int F32R_V = 0, F32R_W = 1, F32R_YV = 2, F32R_YA = 3, F32R_EV = 4, F32R_EA = 5, F32R_W2V = 6, F32R_W2A = 7,
+              F32R_Y2V = 8, F32R_Y2A = 9, F32R_E2V = 10, F32R_E2A = 11, F32R_PD = 12, F32R_VECS = 13;
 
 // ---- environment switches --------------------------------------------------------------
 // The release library reads exactly the switches of kTuningSwitches (wv_api.hip; documented one by one in
@@ -249,6 +255,10 @@ void launch_gemm(hipStream_t st, const GemmArgsF& a, bool a_kcontig, bool b_kcon
 void launch_resid(Problem& p, hipStream_t st, int slot0, int nb);
 void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha);
 void launch_trace(Problem& p, hipStream_t st, int slot0, int nb);
+void launch_gram_matvec2(Problem& p, hipStream_t st, int slot0, int nb, const double* w1, const double* w2, double* y1,
+                         double* y2, int64_t vec_stride, int64_t alpha_stride);
+void launch_f32_refine(Problem& p, hipStream_t st, int slot0, int nb);
+int f32_order();
 void launch_reduce(Problem& p, hipStream_t st, int slot0, int nb, bool with_grad);
 int trace_nwg(const Problem& p, int nb);
 int trace_part_stride(const Problem& p);

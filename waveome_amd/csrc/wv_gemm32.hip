@@ -136,6 +136,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  // Long contractions in float32 lose digits to the accumulation itself: 2048 dependent roundings at K = 8192, each of the
+  // size of the running sum - that, times the condition number, is what the float32 factor's error E is made of
+  // (tools/probe_f32_budget.py: |E|_F^2 = 0.46 at N = 16384, cond 6e4; 5e-4 with this).  So the MFMA accumulators are only
+  // ever FLUSH chunks (512 k, 128 roundings) old: after that they are added into float64 sums and cleared - 64 conversions
+  // + 64 float64 adds per 2048 MFMAs; the product leaves the kernel rounded to float32 once.  Measured at C5 (8 fits,
+  // N = 16384, profiles/r05_f32_sweep.txt): FLUSH 4 / 8 / 16 cost 12 / 5 / 1 ms of 356 and leave the corrected LML 2e-8 /
+  // 4e-8 / 8e-8 from float64 (2e-5 without).
+  constexpr int FLUSH = 16;
+  double dacc[4][4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dacc[i][j][r] = 0.0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dacc[i][j][r] += (double)acc[i][j][r];
+        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
 
   // per-wave contraction range at 64-row / 64-column granularity (triangular operands, lower-only products)
   int wkb = kb, wke = ke;
@@ -186,12 +211,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
       TA::sstore(sA[cur ^ 1], ra, tid);
       TB::sstore(sB[cur ^ 1], rb, tid);
     }
+    if ((c & (FLUSH - 1)) == FLUSH - 1) flush();
     __syncthreads();
   }
+  flush();
 
   // ---- epilogue: C = beta C + alpha acc, staged through LDS so that C moves as full rows ----
   float* __restrict__ C = g.C + (int64_t)b * g.sC;
-  const float alpha = (float)g.alpha, beta = (float)g.beta;
+  const float beta = (float)g.beta;
   constexpr int QUADS = BN / 4;             // float4 per row
   constexpr int NROWIT = 64 * QUADS / 256;  // = 8
 #pragma unroll
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            smem[(i * 16 + 4 * fk + r) * LDC + wn * 64 + j * 16 + fr] = alpha * acc[i][j][r];
+            smem[(i * 16 + 4 * fk + r) * LDC + wn * 64 + j * 16 + fr] = (float)(g.alpha * dacc[i][j][r]);
     }
     __syncthreads();
     if (TOUT != 1) {

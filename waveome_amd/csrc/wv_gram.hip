@@ -814,7 +814,11 @@ constexpr int TRACE_TPW = 4;  // tiles per workgroup
 // `quad` instead of reducing them - trace_group_kernel then adds the tiles of every group of TRACE_TPW in the order a
 // TRACE_TPW-tile workgroup would have, so that a gradient's reduction tree - and with it a fit's whole trajectory -
 // does not depend on how many fits share the launch.
-template <typename R, bool MULTI, bool MASKED, bool PROD = true, bool W4 = false, bool QUADOUT = false>
+// KSUM (float32 contexts): the workgroup also accumulates sum_ij w_ij W_ij K_y,ij - K_y recomputed in float64 on the tile
+// like the Gram pass does - into one more sum slot (index n_red) and writes it as column n_params of its record (records
+// are n_params + 1 wide then).  It is the first-order correction that makes the float32 factor's LML a float64 number
+// (reduce_kernel).
+template <typename R, bool MULTI, bool MASKED, bool PROD = true, bool W4 = false, bool QUADOUT = false, bool KSUM = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(const DevSpec* __restrict__ specs,
                                                     const int32_t* __restrict__ slot_spec,
                                                     const double* __restrict__ F, const double* __restrict__ FC,
@@ -827,7 +831,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
                                                     const int32_t* __restrict__ spec_span,
                                                     const int32_t* __restrict__ col,
                                                     const uint8_t* __restrict__ mask,
-                                                    double* __restrict__ quad_out = nullptr, int quad_stride = 0) {
+                                                    double* __restrict__ quad_out = nullptr, int quad_stride = 0,
+                                                    const double* __restrict__ pdiag_all = nullptr, int64_t pdiag_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
@@ -842,10 +847,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
   double* tab = smem;
   double* fi = smem + EXPTAB_DOUBLES;
   double* fj = fi + sp->n_feat * GT;
-  double* red = fj + sp->n_feat * GT;  // [nred][64 quads]
-  double* pacc = red + nred * 64;      // [np]
+  double* red = fj + sp->n_feat * GT;  // [nred (+ 1: KSUM)][64 quads]
+  constexpr int NX = KSUM ? 1 : 0;
+  double* pacc = red + (nred + NX) * 64;      // [np]
   stage_exp_table(tab, tid);
-  for (int q = tid; q < nred * 64; q += 256) red[q] = 0.0;
+  for (int q = tid; q < (nred + NX) * 64; q += 256) red[q] = 0.0;
   for (int q = tid; q < np; q += 256) pacc[q] = 0.0;
   TileCtx t{fi, fj, tab + (tid & 31), FC + (int64_t)b * max_fact * 4, tid >> 4, tid & 15};
   auto contribute = [&](int slot, double v) {
@@ -883,14 +889,22 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
         const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
         double m = (i > j) ? 1.0 : ((i == j) ? 0.5 : 0.0);
         if (MASKED ? (seen[i] == 0 || seen[j] == 0) : (i >= N || j >= N)) m = 0.0;
+        // (KSUM: the diagonal of Mt'Mt in float64 - the float32 product's diagonal carries a small systematic error that
+        //  would enter the corrected value N-fold)
+        if (KSUM && i == j && pdiag_all) kv[c] = pdiag_all[(int64_t)b * pdiag_stride + i];
         w[a][c] = m * (ai * aj[c] - kv[c]);
         if (i == j) snoise += w[a][c];
       }
     }
     if (ti == tj) contribute(nred - 1, snoise);  // (workgroup-uniform branch)
+    double wk = 0.0;   // (KSUM) this thread's share of sum w W K_y over the tile
+    if (KSUM && ti == tj) wk = snoise * theta_all[(int64_t)b * np + sp->noise_param];  // K_y's diagonal carries the noise
 
     for (int term = 0; term < sp->n_terms; ++term) {
       const int f0 = sp->term_start[term], f1 = sp->term_start[term + 1];
+      // (KSUM) sum w k_term comes for free from the gradient sums when a factor g of the term has a trainable variance
+      // and k_g = var_g x (what its variance sum weights): sum w k_term = var_g s0_g.  Otherwise the term is evaluated.
+      bool term_done = !KSUM;
       for (int g = f0; g < f1; ++g) {
         const DevFactor fg = sp->factors[g];
         if (fg.trainable == 0) continue;
@@ -910,17 +924,30 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
         contribute(fg.sbase, s[0]);
         if (fg.nsum > 1) contribute(fg.sbase + 1, s[1]);
         if (fg.nsum > 2) contribute(fg.sbase + 2, s[2]);
+        if (KSUM && !term_done && (fg.trainable & 1) && fg.type != WV_K_POLY && fg.type != WV_K_EMPTY) {
+          wk = fma(t.fc[4 * g + 1], s[0], wk);
+          term_done = true;
+        }
+      }
+      if (KSUM && !term_done) {   // (every variance of the term frozen, or only a Polynomial's trainable)
+        double ks[4][4];
+        kernel_sum_tile<MULTI>(sp, t, 1ull << term, ks);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) wk = fma(w[a][c], ks[a][c], wk);
       }
     }
+    if constexpr (KSUM) contribute(nred, wk);
   }
   __syncthreads();
   if constexpr (QUADOUT) {  // (tpw == 1: this workgroup's tile is blockIdx.x; a skipped zero tile leaves zeros)
     double* q = quad_out + ((int64_t)blockIdx.y * ntiles + blockIdx.x) * quad_stride;
-    for (int i = tid; i < nred * 64; i += 256) q[i] = red[i];
+    for (int i = tid; i < (nred + NX) * 64; i += 256) q[i] = red[i];
     return;
   }
   // one 64-lane reduction per slot (wave w takes slots w, w + 4, ...); the total goes back into red[slot * 64]
-  for (int sidx = wave; sidx < nred; sidx += 4) {
+  for (int sidx = wave; sidx < nred + NX; sidx += 4) {
     const double v = wave_sum(red[sidx * 64 + lane]);
     if (lane == 0) red[sidx * 64] = v;
   }
@@ -935,8 +962,9 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
   }
   if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[(nred - 1) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
-  double* out = part + ((int64_t)b * part_stride + blockIdx.x) * np;
+  double* out = part + ((int64_t)b * part_stride + blockIdx.x) * (np + NX);
   for (int p = tid; p < np; p += 256) out[p] = pacc[p];
+  if (KSUM && tid == 0) out[np] = red[nred * 64];
 }
 
 // Few fits in flight: the tiles were traced one per workgroup (trace_kernel<..., QUADOUT>); group g adds the per-quad
@@ -946,17 +974,18 @@ __global__ __launch_bounds__(256, MULTI ? 2 : (W4 ? 4 : 3)) void trace_kernel(co
 __global__ __launch_bounds__(256) void trace_group_kernel(const DevSpec* __restrict__ specs,
                                                           const int32_t* __restrict__ slot_spec,
                                                           const double* __restrict__ quad, double* __restrict__ part,
-                                                          int slot0, int ntiles, int quad_stride, int part_stride) {
+                                                          int slot0, int ntiles, int quad_stride, int part_stride,
+                                                          int ksum) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = slot0 + blockIdx.y, g = blockIdx.x;
   const DevSpec* __restrict__ sp = specs + slot_spec[b];
   const int np = sp->n_params, nred = sp->n_red;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* red = smem;          // [nred] totals
-  double* pacc = smem + nred;  // [np]
+  double* red = smem;          // [nred (+ 1: float32 contexts, trace_kernel's KSUM slot)] totals
+  double* pacc = smem + nred + ksum;  // [np]
   for (int q = tid; q < np; q += 256) pacc[q] = 0.0;
   const int t0 = g * TRACE_TPW, t1 = min(ntiles, t0 + TRACE_TPW);
-  for (int sidx = wave; sidx < nred; sidx += 4) {
+  for (int sidx = wave; sidx < nred + ksum; sidx += 4) {
     double a = 0.0;
     for (int t = t0; t < t1; ++t) a += quad[((int64_t)blockIdx.y * ntiles + t) * quad_stride + sidx * 64 + lane];
     const double v = wave_sum(a);
@@ -972,8 +1001,9 @@ __global__ __launch_bounds__(256) void trace_group_kernel(const DevSpec* __restr
   }
   if (tid == 0) __hip_atomic_fetch_add(&pacc[sp->noise_param], red[nred - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
-  double* out = part + ((int64_t)b * part_stride + g) * np;
+  double* out = part + ((int64_t)b * part_stride + g) * (np + ksum);
   for (int p = tid; p < np; p += 256) out[p] = pacc[p];
+  if (ksum && tid == 0) out[np] = red[nred];
 }
 
 static void launch_features(Problem& p, hipStream_t st, int slot0, int nb) {
@@ -1015,6 +1045,95 @@ static void launch_gram_t(Problem& p, hipStream_t st, R* Kall, int slot0, int nb
 #undef WV_GRAM_LAUNCH
 }
 
+// y1 = K_y w1, y2 = K_y w2 with K_y recomputed in float64 tile by tile (never stored): one workgroup per 64-row tile row,
+// walking all tile columns.  Rows that are padding (or whose output is missing) are identity rows / columns of K_y.  Used by
+// the float32 contexts' second-order value correction (launch_f32_refine, wv_chol.hip): w1 = Mt'v, w2 = alpha.
+template <bool MULTI, bool MASKED>
+__global__ __launch_bounds__(256, 3) void gram_matvec2_kernel(const DevSpec* __restrict__ specs,
+                                                              const int32_t* __restrict__ slot_spec,
+                                                              const double* __restrict__ F, const double* __restrict__ FC,
+                                                              const double* __restrict__ theta_all,
+                                                              const double* __restrict__ w1_all, const double* __restrict__ w2_all,
+                                                              double* __restrict__ y1_all, double* __restrict__ y2_all,
+                                                              int64_t vec_stride, int64_t alpha_stride, int64_t N, int64_t Npad,
+                                                              int max_feat, int max_fact, int slot0,
+                                                              const int32_t* __restrict__ col, const uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = slot0 + blockIdx.y, ti = blockIdx.x;
+  const DevSpec* __restrict__ sp = specs + slot_spec[b];
+  const double* th = theta_all + (int64_t)b * sp->n_params;
+  const uint8_t* seen = MASKED ? mask + (int64_t)col[b] * Npad : nullptr;
+  const int tid = threadIdx.x;
+  double* tab = smem;
+  double* fi = smem + EXPTAB_DOUBLES;
+  double* fj = fi + sp->n_feat * GT;
+  const double* Fr = F + (int64_t)b * 2 * max_feat * Npad;
+  const double* Fc = Fr + (int64_t)max_feat * Npad;
+  const double* w1 = w1_all + (int64_t)b * vec_stride;
+  const double* w2 = w2_all + (int64_t)b * alpha_stride;
+  stage_exp_table(tab, tid);
+  stage_from_table(fi, Fr, sp->n_feat, Npad, ti * GT, tid);
+  TileCtx t{fi, fj, tab + (tid & 31), FC + (int64_t)b * max_fact * 4, tid >> 4, tid & 15};
+  const double noise = th[sp->noise_param];
+  double y1[4] = {0, 0, 0, 0}, y2[4] = {0, 0, 0, 0};
+  bool live_i[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
+    live_i[a] = MASKED ? seen[i] != 0 : i < N;
+  }
+  const int ntile = (int)(Npad / GT);
+  for (int tj = 0; tj < ntile; ++tj) {
+    __syncthreads();
+    stage_from_table(fj, Fc, sp->n_feat, Npad, tj * GT, tid);
+    __syncthreads();
+    double sum[4][4];
+    kernel_sum_tile<MULTI>(sp, t, ~0ull, sum);
+    double a1[4], a2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t j = (int64_t)tj * GT + 4 * t.tx + c;
+      const bool lj = MASKED ? seen[j] != 0 : j < N;
+      a1[c] = lj ? w1[j] : 0.0;
+      a2[c] = lj ? w2[j] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        y1[a] = fma(sum[a][c], a1[c], y1[a]);
+        y2[a] = fma(sum[a][c], a2[c], y2[a]);
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {   // the sixteen threads of a row are sixteen consecutive lanes
+      y1[a] += __shfl_xor(y1[a], o, 64);
+      y2[a] += __shfl_xor(y2[a], o, 64);
+    }
+    if (t.tx == 0) {
+      const int64_t i = (int64_t)ti * GT + t.ty + 16 * a;
+      const double u1 = w1[i], u2 = w2[i];
+      y1_all[(int64_t)b * vec_stride + i] = live_i[a] ? y1[a] + noise * u1 : u1;
+      y2_all[(int64_t)b * vec_stride + i] = live_i[a] ? y2[a] + noise * u2 : u2;
+    }
+  }
+}
+
+void launch_gram_matvec2(Problem& p, hipStream_t st, int slot0, int nb, const double* w1, const double* w2, double* y1,
+                         double* y2, int64_t vec_stride, int64_t alpha_stride) {
+  const dim3 grid((unsigned)(p.Npad / GT), nb), blk(256);
+  const size_t sh = gram_lds_bytes(p);
+#define WV_GMV(MU, MA)                                                                                                   \
+  if (exp_table_ok<gram_matvec2_kernel<MU, MA>>())                                                                       \
+  hipLaunchKernelGGL((gram_matvec2_kernel<MU, MA>), grid, blk, sh, st, p.dspec, p.dslotspec, p.dfeat, p.dfconst, p.dtheta, \
+                     w1, w2, y1, y2, vec_stride, alpha_stride, p.N, p.Npad, p.max_feat, p.max_fact, slot0, p.dcol, p.dmask)
+  if (p.any_multidim) { if (p.dmask) { WV_GMV(true, true); } else { WV_GMV(true, false); } }
+  else { if (p.dmask) { WV_GMV(false, true); } else { WV_GMV(false, false); } }
+#undef WV_GMV
+}
+
 void launch_gram_masked(Problem& p, hipStream_t st, int slot0, int nb, uint64_t term_mask, double diag) {
   launch_features(p, st, slot0, nb);  // (the parameter rows of these slots may have changed since the last call)
   if (p.f32) launch_gram_t<float>(p, st, p.Kbuf32, slot0, nb, 0, term_mask, diag);
@@ -1038,6 +1157,9 @@ int trace_part_stride(const Problem& p) { return p.ntiles(); }
 
 template <typename RT, bool MU, bool MA, bool PROD, bool W4>
 static void trace_launch(Problem& p, hipStream_t st, const RT* kbuf, int slot0, int nb) {
+  constexpr bool KS = std::is_same<RT, float>::value;   // float32 contexts: + the K_y-weighted sum (Problem::max_red counts its slot)
+  // (WV_F32_ORDER >= 2: launch_f32_refine left the float64 diagonal of Mt'Mt there)
+  const double* pdiag = (p.df32r && f32_order() >= 2) ? p.df32r + (int64_t)F32R_PD * p.Npad : nullptr;
   // few fits in flight: one tile per workgroup, per-quad accumulators to p.dquad, groups summed by trace_group_kernel
   double* quad = nullptr;
   if (nb <= FEW_FITS && nb <= p.quad_fits && p.dquad)
@@ -1046,19 +1168,19 @@ static void trace_launch(Problem& p, hipStream_t st, const RT* kbuf, int slot0, 
   const size_t sh = gram_lds_bytes(p) + ((size_t)64 * p.max_red + p.np_stride) * sizeof(double);
   const dim3 blk(256);
   if (quad) {
-    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, true>>()) return;
-    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, true>), dim3(p.ntiles(), nb), blk, sh, st, p.dspec, p.dslotspec,
+    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, true, KS>>()) return;
+    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, true, KS>), dim3(p.ntiles(), nb), blk, sh, st, p.dspec, p.dslotspec,
                        p.dfeat, p.dfconst, p.dtheta, kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact, slot0,
                        p.ntiles(), 1, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr, p.dspec_span, p.dcol,
-                       p.dmask, quad, (int)p.quad_stride);
+                       p.dmask, quad, (int)p.quad_stride, pdiag, (int64_t)F32R_VECS * p.Npad);
     hipLaunchKernelGGL(trace_group_kernel, dim3(trace_nwg(p, nb), nb), blk, sizeof(double) * (p.max_red + p.np_stride), st,
-                       p.dspec, p.dslotspec, quad, p.dpart, slot0, p.ntiles(), (int)p.quad_stride, trace_part_stride(p));
+                       p.dspec, p.dslotspec, quad, p.dpart, slot0, p.ntiles(), (int)p.quad_stride, trace_part_stride(p), KS ? 1 : 0);
   } else {
-    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, false>>()) return;
-    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, false>), dim3(trace_nwg(p, nb), nb), blk, sh, st, p.dspec,
+    if (!exp_table_ok<trace_kernel<RT, MU, MA, PROD, W4, false, KS>>()) return;
+    hipLaunchKernelGGL((trace_kernel<RT, MU, MA, PROD, W4, false, KS>), dim3(trace_nwg(p, nb), nb), blk, sh, st, p.dspec,
                        p.dslotspec, p.dfeat, p.dfconst, p.dtheta, kbuf, p.dalpha, p.dpart, p.N, p.Npad, p.max_feat, p.max_fact,
                        slot0, p.ntiles(), TRACE_TPW, trace_part_stride(p), p.n_span_tables ? p.dspans : nullptr,
-                       p.dspec_span, p.dcol, p.dmask, nullptr, 0);
+                       p.dspec_span, p.dcol, p.dmask, nullptr, 0, pdiag, (int64_t)F32R_VECS * p.Npad);
   }
 }
 

@@ -13,29 +13,26 @@ from . import kernels as K
 _precision = "float64"
 
 
-FLOAT32_LOSS_REL_ERR = 1e-4   # measured: 6.9e-5 at N = 16384, Matern-3/2 (profiles/r03_bench_c5.json); 4e-7 at N = 8192
+FLOAT32_LOSS_REL_ERR = 1e-6   # measured: 1.4e-7 at N = 16384, Matern-3/2 (profiles/r05_bench_c5.json); 6e-8 at N = 2048
 
 
 def set_precision(precision: str = "float64"):
     """Default floating point precision of contexts created afterwards (waveome/utilities.py:34-49).
 
-    "float32" is a THROUGHPUT mode, not a parity mode: the N x N work matrices and their MFMA products are float32
-    (the 128-row leaves, the solves and every reduction stay float64), which doubles the matrix rate (C5: 108 TFLOP/s)
-    and carries a relative error of up to ~1e-4 in the loss / LML at N ~ 16384 (95 % of it in log|K_y|: the Schur
-    complements are STORED in float32; refining alpha = K_y^-1 r would not touch it).  The reference's float32
-    (TensorFlow's `set_default_float`) has the same order of error and no statement about it either.  Consequences,
-    stated here because nothing else would tell a user: BIC / log-Bayes-factor differences below ~1e-4 |LML| are noise
-    in this mode; models fitted in different precisions must not be ranked against each other; the north-star tolerance
-    (LML within 1e-6 of the float64 reference) holds in "float64" only.  A warning says so once per process."""
+    "float32": the N x N work matrices and the operands of their MFMA products are float32 (the 128-row leaves, the
+    solves and every reduction stay float64), which nearly doubles the matrix rate (C5: 100 TFLOP/s against 60).  Since
+    round 5 it is a PARITY mode for well-conditioned problems: the products accumulate through float64 sums (flushed every
+    512 k), and the value of an evaluation is corrected back to float64 through the exact identity
+    log|K_y| = -2 log|M| + log|I + E|, E = M K_y M' - I, with K_y recomputed in float64 (first order in E from the gradient
+    pass at no cost; `WV_F32_ORDER=2|4` adds higher orders).  Measured against the float64 path: loss / LML 1.4e-7 relative
+    and gradient 1e-6 of its largest component at N = 16384 (BASELINE C5), <= 3e-7 for cond(K_y) ~ 5e4 at every size tried;
+    what is left scales with (cond(K_y) x 6e-8)^2 - an ill-conditioned K_y (cond > 1e6: noise variance 0.01 under unit-variance
+    kernels at N > 4000) still loses digits (1e-5 ... 1e-4; 1e-6 ... 1e-5 with WV_F32_ORDER=4).  The north-star tolerance (LML
+    within 1e-6 of the float64 reference) is asserted for float32 in tests/test_gpu_f32.py.  Value-only evaluations (`wv_lml`)
+    run the gradient pipeline on a float32 context (the correction needs K_y^-1), so they cost what value + gradient costs."""
     global _precision
     if precision not in ["float32", "float64"]:
         raise ValueError("Precision must be either 'float32' or 'float64'")
-    if precision == "float32" and _precision != "float32":
-        import warnings
-
-        warnings.warn("waveome_amd: float32 is a throughput mode - losses / LML carry a relative error of up to "
-                      f"~{FLOAT32_LOSS_REL_ERR:g} (float64: 1e-10); do not compare BIC values across precisions",
-                      stacklevel=2)
     _precision = precision
 
 
