@@ -198,6 +198,44 @@ def test_block_skipping_on_the_wide_hand_scheduled_tiles(tmp_path, units, per_un
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("units,per_unit", [(12, 40), (7, 150), (16, 64)])
+def test_block_skipping_on_a_float32_context(units, per_unit):
+    """float32 contexts used to ignore the span tables.  The float32 GEMM now trims its contraction
+    ranges like the float64 one (flush points of its float64 partial sums sit on the absolute chunk grid, so leaving out
+    exact zeros changes no bit): value, gradient, M and K_y^-1 equal the dense float32 path bit for bit, and the float64
+    oracle to the float32 path's tolerances."""
+    from oracle import gp_oracle as o
+    from waveome_amd.engine import Context, Problem
+
+    X, Y = _longitudinal(3, units, per_unit, True)
+    spec = ModelSpec(_block_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
+    rng = np.random.default_rng(1)
+    B = 3
+    U = spec.unconstrain()[None, :] + 0.3 * rng.normal(size=(B, spec.n_trainable))
+    cols = np.arange(B, dtype=np.int32) % Y.shape[1]
+    ctx = Context(0, dtype="float32")
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WV_BLOCKS"] = mode
+        try:
+            p = Problem(ctx, X, Y, spec, max_batch=B)
+        finally:
+            os.environ.pop("WV_BLOCKS", None)
+        f, g, st = p.value_grad(cols, U)
+        assert np.all(st == 0)
+        out[mode] = (f, g, p.dbg_stage(0, spec.constrain(U[0]), 1), np.tril(p.dbg_stage(0, spec.constrain(U[0]), 2)))
+        p.close()
+    ctx.close()
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(a, b)
+    d = spec.to_dict()
+    for b in range(B):
+        fo, go = o.objective(d, U[b], X, Y[:, cols[b]])
+        assert abs(out["1"][0][b] - fo) <= 1e-6 * max(1.0, abs(fo))
+        assert np.max(np.abs(out["1"][1][b] - go)) <= 1e-4 * max(1.0, np.max(np.abs(go)))
+
+
+@pytest.mark.gpu
 def test_block_and_dense_structures_share_a_batch():
     """A multi-structure work queue mixes block-diagonal and dense candidates in one launch (as the kernel search
     does): every slot follows its own structure's table."""

@@ -581,7 +581,7 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
   WV_HIP_TRY(hipMemset(p.dspec_span, 0xff, sizeof(int32_t) * p.spec_cap));  // -1: dense
   {
     const char* e = tuning_env("WV_BLOCKS");
-    if (!(e && std::atoi(e) == 0) && !p.f32) {  // (the float32 GEMM does not read the tables)
+    if (!(e && std::atoi(e) == 0)) {
       p.hX.resize((size_t)N * D);
       WV_HIP_TRY(hipMemcpy(p.hX.data(), X, sizeof(double) * N * D, x_is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
       p.span_table_of_col.assign(D, -1);

@@ -119,6 +119,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
   if (g.klo_mode == 2) kb = max(kb, n0 + g.koff);
   if (g.khi_mode == 1) ke = min(ke, m0 + BM + g.koff);
   if (g.khi_mode == 2) ke = min(ke, n0 + BN + g.koff);
+  // Block structure (GemmArgsT::spans, as in wv_gemm.hip): only the k that can meet a non-zero of both operands
+  const int32_t* span_tab = nullptr;
+  if (g.spans) {
+    const int t = g.spec_span[g.slot_spec[g.slot0 + b]];
+    if (t >= 0) {
+      span_tab = g.spans + (int64_t)t * g.span_nblk * 2;
+      int lo_r = 1 << 30, hi_r = 0, lo_c = 1 << 30, hi_c = 0;
+      const int gr0 = (g.sp_r0 + m0) >> 6, gr1 = (g.sp_r0 + min(m0 + BM, g.M) - 1) >> 6;
+      const int gc0 = (g.sp_c0 + n0) >> 6, gc1 = (g.sp_c0 + min(n0 + BN, g.N) - 1) >> 6;
+      for (int q = gr0; q <= gr1; ++q) { lo_r = min(lo_r, span_tab[2 * q]); hi_r = max(hi_r, span_tab[2 * q + 1]); }
+      for (int q = gc0; q <= gc1; ++q) { lo_c = min(lo_c, span_tab[2 * q]); hi_c = max(hi_c, span_tab[2 * q + 1]); }
+      kb = max(kb, max(lo_r, lo_c) - g.sp_k0);
+      ke = max(kb, min(ke, min(hi_r, hi_c) - g.sp_k0));
+      if (ke == kb && g.beta == 1.0 && TOUT == 0) return;  // C += 0
+    }
+  }
   // chunks are 32 wide while operand extents are multiples of 64: round the range outwards onto the
   // chunk grid anchored at g.kb (the extra rows are zeros of the triangular operand or inside [g.kb, g.ke))
   kb = g.kb + (kb - g.kb) / KC * KC;
@@ -171,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
     if (g.khi_mode == 1) wke = min(wke, wr + 64 + g.koff);
     if (g.khi_mode == 2) wke = min(wke, wc + 64 + g.koff);
     if (g.tri && wc + g.tri_off > wr + 63) wke = wkb;
+    if (span_tab) {  // the wave's own 64 rows and 64 columns
+      const int qr = (g.sp_r0 + min(wr, g.M - 1)) >> 6, qc = (g.sp_c0 + min(wc, g.N - 1)) >> 6;
+      wkb = max(wkb, max(span_tab[2 * qr], span_tab[2 * qc]) - g.sp_k0);
+      wke = min(wke, min(span_tab[2 * qr + 1], span_tab[2 * qc + 1]) - g.sp_k0);
+    }
   }
   f4 ra[TA::NLOAD], rb[TB::NLOAD];
   const int nchunk = (ke - kb + KC - 1) / KC;
@@ -211,7 +232,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
       TA::sstore(sA[cur ^ 1], ra, tid);
       TB::sstore(sB[cur ^ 1], rb, tid);
     }
-    if ((c & (FLUSH - 1)) == FLUSH - 1) flush();
+    // (flush points sit on the absolute chunk grid: a contraction range trimmed by block spans - exact zeros left out -
+    //  keeps the same partial sums, so block and dense products agree bit for bit)
+    if ((((kc0 - g.kb) / KC) & (FLUSH - 1)) == (kstep > 0 ? FLUSH - 1 : 0)) flush();
     __syncthreads();
   }
   flush();
