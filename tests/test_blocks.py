@@ -104,11 +104,14 @@ def _block_kernel():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sort", [True, False])
-@pytest.mark.parametrize("units,per_unit", [(12, 40), (7, 150)])
+@pytest.mark.parametrize("units,per_unit", [(12, 40), (7, 150), (16, 64), (5, 128), (6, 192)])
 def test_block_skipping_is_bit_identical_to_dense_and_matches_oracle(units, per_unit, sort):
     from oracle import gp_oracle as o
     from waveome_amd.engine import Context, Problem
 
+    # (units of 64 / 128 rows end on the boundaries of the 128-row recursion nodes: whole nodes decouple - the recursion
+    #  drops S, the update, T and M21 there and factors runs of independent 128-nodes in one launch; 192-row units
+    #  decouple at every third boundary only)
     X, Y = _longitudinal(3, units, per_unit, sort)
     spec = ModelSpec(_block_kernel(), 3, K.GaussianLikelihood(), K.ConstantMean())
     assert spec.block_column() == 2
@@ -165,7 +168,7 @@ np.savez(sys.argv[2], f=f, g=g, st=st, lml=lml, M=p.dbg_stage(0, th, 1), Kinv=np
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("units,per_unit,sort", [(7, 150, True), (12, 40, True), (9, 100, False)])
+@pytest.mark.parametrize("units,per_unit,sort", [(7, 150, True), (12, 40, True), (9, 100, False), (16, 64, True), (6, 192, True)])
 def test_block_skipping_on_the_wide_hand_scheduled_tiles(tmp_path, units, per_unit, sort):
     """three fits select the small 64 x 64 tile, so the test above never reaches the 128-wide kernels whose
     waves own SPREAD fragments (the union of two 64-row and two 64-column granules' spans, then the trimming of the

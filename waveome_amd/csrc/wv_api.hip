@@ -360,11 +360,40 @@ static int register_block_structure(Problem& p, int si) {
       WV_HIP_TRY(hipMemcpy(p.dspans + (int64_t)p.n_span_tables * sp.size(), sp.data(), sizeof(int32_t) * sp.size(),
                            hipMemcpyHostToDevice));
       p.span_table_of_col[col] = p.n_span_tables++;
+      p.hspan_tabs.push_back(sp);
     }
     table = p.span_table_of_col[col];
   }
   // (a new entry is referenced by no slot yet, so kernels in flight do not read it)
   WV_HIP_TRY(hipMemcpy(p.dspec_span + si, &table, sizeof(int32_t), hipMemcpyHostToDevice));
+  if ((int)p.spec_table.size() <= si) p.spec_table.resize(si + 1, -1);
+  p.spec_table[si] = table;
+  // boundaries at which every structure of the problem decouples (Problem::decoupled)
+  const int64_t ng = p.Npad / 64;
+  bool all_block = true;
+  for (int t : p.spec_table) all_block &= t >= 0;
+  if (!all_block) {
+    // a dense structure: every product runs again (and rewrites the M21 blocks) for good
+    std::fill(p.decoupled.begin(), p.decoupled.end(), 0);
+    if (p.decoupled.empty()) p.decoupled.assign(ng + 1, 0);
+    p.ever_dense = true;
+  } else if (!p.ever_dense) {
+    p.decoupled.assign(ng + 1, 1);
+    p.decoupled[0] = p.decoupled[ng] = 0;
+    for (int t : p.spec_table) {
+      const std::vector<int32_t>& sp = p.hspan_tabs[t];
+      int32_t hi_below = 0;
+      for (int64_t g = 1; g < ng; ++g) {   // rows below 64 g reach up to hi_below; rows from 64 g on reach down to lo_above
+        hi_below = std::max(hi_below, sp[2 * (g - 1) + 1]);
+        if (hi_below > 64 * g) p.decoupled[g] = 0;
+      }
+      int32_t lo_above = INT32_MAX;
+      for (int64_t g = ng - 1; g >= 1; --g) {
+        lo_above = std::min(lo_above, sp[2 * g]);
+        if (lo_above < 64 * g) p.decoupled[g] = 0;
+      }
+    }
+  }
   return WV_OK;
 }
 

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   __shared__ W dinfo[16 * DINFO];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
+  o += 2 * NB * (int)blockIdx.y;   // (a run of independent 128-nodes in one launch: block structures, fi_node)
   const int64_t mat = Npad * Npad;
   const R* K = Kall + (int64_t)b * mat;
   R* M = Mall + (int64_t)b * mat;
@@ -541,15 +542,25 @@ extern "C" __attribute__((visibility("default"))) int wv_dbg_stamps(unsigned lon
 }
 #endif
 
-void launch_potrf128(Problem& p, hipStream_t st, int slot0, int nb, int o) {
+void launch_potrf128(Problem& p, hipStream_t st, int slot0, int nb, int o, int count = 1) {
   p.timer.begin(st, ST_POTRF_DIAG);
   if (p.f32)
-    hipLaunchKernelGGL(potrf128_kernel<float>, dim3(nb), dim3(256), 0, st, p.Kbuf32, p.Mbuf32, p.MTbuf32, p.dlogdet,
+    hipLaunchKernelGGL(potrf128_kernel<float>, dim3(nb, count), dim3(256), 0, st, p.Kbuf32, p.Mbuf32, p.MTbuf32, p.dlogdet,
                        p.dstatus, p.Npad, p.nblk(), slot0, o);
   else
-    hipLaunchKernelGGL(potrf128_kernel<double>, dim3(nb), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
+    hipLaunchKernelGGL(potrf128_kernel<double>, dim3(nb, count), dim3(256), 0, st, p.Kbuf, p.Mbuf, p.MTbuf, p.dlogdet,
                        p.dstatus, p.Npad, p.nblk(), slot0, o);
   p.timer.end(st);
+}
+
+// Block structures: are the two sides of a split of node (o, n) at o + h1 independent in every structure of the problem
+// (Problem::decoupled)?  And is the whole node a run of independent 128-nodes?
+static bool node_splits_free(const Problem& p, int64_t o, int64_t h1) { return p.decoupled_at(o + h1); }
+static bool node_is_independent_leaves(const Problem& p, int64_t o, int64_t n) {
+  if (n % (2 * NB) != 0 || n < 4 * NB) return false;
+  for (int64_t b = o + 2 * NB; b < o + n; b += 2 * NB)
+    if (!p.decoupled_at(b)) return false;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1158,6 +1169,18 @@ static void fi_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   }
   const int64_t Np = p.Npad, mat = Np * Np;
   const int64_t h1 = split_point(n), h2 = n - h1;
+  // Block structures (Problem::decoupled): K_y(rows >= o + h1, columns < o + h1) is structurally zero in every structure
+  // of the problem - S, the update, T and M21 vanish (M21 stays the zero block it was created as), the children are
+  // independent; a node that is nothing but independent 128-nodes is ONE leaf launch.
+  if (node_is_independent_leaves(p, o, n)) {
+    launch_potrf128(p, st, slot0, nb, (int)o, (int)(n / (2 * NB)));
+    return;
+  }
+  if (node_splits_free(p, o, h1)) {
+    fi_node<R>(p, st, slot0, nb, o, h1);
+    fi_node<R>(p, st, slot0, nb, o + h1, h2);
+    return;
+  }
   const MatBufs<R> mb = mat_bufs<R>(p);
   R* K0 = mb.K + (int64_t)slot0 * mat;
   R* M0 = mb.M + (int64_t)slot0 * mat;
@@ -1267,11 +1290,22 @@ static void fv_node(Problem& p, hipStream_t st, int slot0, int nb, int64_t o, in
   R* MT0 = mb.MT + (int64_t)slot0 * mat;
   R* S0 = mb.P + (int64_t)slot0 * p.pbuf_elems();
   const int64_t sS = p.pbuf_elems();
+  if (node_is_independent_leaves(p, o, n)) {   // block structures: independent 128-nodes - one leaf launch, one substitution
+    launch_potrf128(p, st, slot0, nb, (int)o, (int)(n / (2 * NB)));
+    p.timer.begin(st, ST_SOLVE);
+    hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(n / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o, n, slot0);
+    p.timer.end(st);
+    return;
+  }
   fi_node<R>(p, st, slot0, nb, o, h1);
   p.timer.begin(st, ST_SOLVE);
   hipLaunchKernelGGL(trmv_sub_kernel<R>, dim3((unsigned)(h1 / 16), nb), dim3(256), 0, st, mb.M, p.dr, p.dz, Np, o, h1,
                      slot0);
   p.timer.end(st);
+  if (node_splits_free(p, o, h1)) {   // S = 0: nothing reaches the right-hand side or the Schur complement of the right block
+    fv_node<R>(p, st, slot0, nb, o + h1, h2);
+    return;
+  }
   {  // S = A21 * M11'   written transposed (same product as in fi_node)
     GemmArgsT<R> a = base_args<R>(p, slot0, nb);
     a.A = K0 + (o + h1) * Np + o;

@@ -165,6 +165,16 @@ struct Problem {
   std::vector<double> hX;             // [N][D]
   std::vector<int> span_table_of_col; // [D] table index or -1
   int n_span_tables = 0;
+  // Independent diagonal blocks (wv_chol.hip, fi_node): decoupled[g] != 0 = in EVERY structure of the problem no row
+  // below 64 g can share a label with a row at or above it, i.e. K_y(rows >= 64 g, columns < 64 g) is structurally zero
+  // for every slot: the recursion then treats the two sides of a split at 64 g as independent problems (no S, no update,
+  // no T, no M21 - those blocks of M stay the zeros they were created as) and factors runs of independent 128-nodes in one
+  // launch.  Recomputed whenever a structure is registered; all zero once a dense structure exists.
+  std::vector<std::vector<int32_t>> hspan_tabs;   // host copies of the span tables
+  std::vector<int32_t> spec_table;                // [specs] table index or -1
+  std::vector<uint8_t> decoupled;                 // [Npad / 64 + 1]
+  bool ever_dense = false;                        // a dense structure was registered at some point: never decouple again
+  bool decoupled_at(int64_t row) const { return !decoupled.empty() && row % 64 == 0 && decoupled[row / 64] != 0; }
   int32_t* dspans = nullptr;          // [D][Npad / 64][2]
   int32_t* dspec_span = nullptr;      // [spec_cap]
   // missing outputs (wv_problem_caps::nan_is_missing): per output column the rows that are observed (1) - masked
