@@ -204,9 +204,9 @@ def cpu_baseline_finish(raw, evals_per_fit):
 def pmc_traffic(fits_per_launch):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process, so
     the figure comes from the committed rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, corrected as
-    MI355X_MICROARCH.md prescribes; profiles/r04_traffic.json, made by tools/make_traffic_json.py) of the same
+    MI355X_MICROARCH.md prescribes; profiles/r05_traffic.json, made by tools/make_traffic_json.py) of the same
     kernel on the same workload, scaled to the fits one launch covers here.  None when the summary is absent."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as fh:

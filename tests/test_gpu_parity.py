@@ -1795,6 +1795,7 @@ def test_every_tile_regime_gives_the_same_bits(tmp_path):
     # (WV_SMALL_FILL=0) and the small tile's last / partial chunks are still hipcc's loop.  The direct comparison of
     # every stream with hipcc's loop on the same operands is test_hand_scheduled_k_loop_against_hipccs_loop below.)
     variants = (("default", {}), ("wide", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1"}),
+                ("wide, full chunks over triangular zeros", {"WV_BN_FILL": "0", "WV_TRI_SPLIT_MIN": "1", "WV_TRIM": "0"}),
                 ("unpaired", {"WV_PAIR": "0"}),  # (trailing update and T as two launches instead of one)
                 ("wide, one launch per lower-only product", {"WV_BN_FILL": "0", "WV_TRI_SPLIT": "0"}),
                 ("128 x 64 tiles", {"WV_SMALL_FILL": "0"}),

@@ -54,7 +54,7 @@ def test_release_library_carries_no_experiments(lib):
     # exercised by tests/test_gpu_parity.py::test_every_tile_regime_gives_the_same_bits); WV_MAX_PARAMS is the name of
     # a limit in an error message, not a switch
     documented = {b"WV_GROUPS", b"WV_BN_FILL", b"WV_SMALL_FILL", b"WV_PAIR", b"WV_TRI_SPLIT", b"WV_TRI_SPLIT_MIN",
-                  b"WV_BLOCKS", b"WV_VALUE_FULL", b"WV_FIT_TRACE", b"WV_F32_ORDER"}
+                  b"WV_BLOCKS", b"WV_VALUE_FULL", b"WV_FIT_TRACE", b"WV_F32_ORDER", b"WV_TRIM"}
     import re
     found = set(re.findall(rb"WV_[A-Z0-9_]+", blob)) - {b"WV_MAX_PARAMS"}
     assert found == documented, (sorted(found - documented), sorted(documented - found))

@@ -1,5 +1,6 @@
-"""A/B of WV_T_SIDE (T = S M11 on a side stream) in child processes: ms per value+gradient round at 512 / 128 / 64 fits,
-headline structure, N = 2048; alternating, three repetitions."""
+"""A/B of one environment switch of the library in child processes (switches are read once per process): ms per
+value + gradient round at 512 / 128 / 64 fits, headline structure, N = 2048; alternating, three repetitions, and a
+checksum of the losses (same bits or not).   python3 tools/probe_env_ab.py WV_TRIM 1 0"""
 import os, subprocess, sys
 CHILD = r'''
 import sys, time
@@ -19,7 +20,8 @@ for nb in (512, 128, 64):
     ctx.synchronize(); out.append((time.perf_counter() - t0) / 8 * 1e3)
 print(" ".join(f"{v:.3f}" for v in out), float(f[:8].sum()))
 '''
+name, vals = sys.argv[1], sys.argv[2:]
 for rep in range(3):
-    for side in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, WV_T_SIDE=side), capture_output=True, check=True)
-        print(f"WV_T_SIDE={side}: ms per round at 512 / 128 / 64 fits, checksum: {r.stdout.decode().strip()}", flush=True)
+    for v in vals:
+        r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, **{name: v}), capture_output=True, check=True)
+        print(f"{name}={v}: ms per round at 512 / 128 / 64 fits, checksum: {r.stdout.decode().strip()}", flush=True)

@@ -28,6 +28,7 @@ static const char* const kTuningSwitches[] = {
     "WV_BLOCKS",         // 0: no zero-block skipping (dense products on block-diagonal structures)
     "WV_VALUE_FULL",     // value-only evaluations through factor + inverse (same LML to rounding, not to the bit)
     "WV_FIT_TRACE",      // host-side timing of a fit loop on stderr (no effect on results)
+    "WV_TRIM",           // 0: no partial-chunk streams beside a triangular operand's diagonal (full chunks over its zeros)
     "WV_F32_ORDER",      // float32 contexts: order of the value correction in E = Mt K_y Mt' - I (1 default; 2, 4: + probe passes)
 };
 const char* tuning_env(const char* name) {

@@ -88,6 +88,7 @@ struct GemmArgsT {
   int32_t ldct, tout;
   int32_t tag;         // 1: launch the separately named instantiation (K_y^-1 = M'M)
   int32_t tiles_live;  // tiles that are launched (lower tiles only when tri)
+  int32_t notrim;      // 1: no partial-chunk streams next to a triangular operand's diagonal (full chunks over the zeros)
 #ifdef WV_EXPERIMENTS   // `make probes` only (wv_gemm.hip): the release kernels have no switch that can change a result
   int32_t latin;       // 0: per-matrix rotation of the launch order, 1: Latin-square skew (release behaviour), 2: both
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
