@@ -22,7 +22,7 @@ backend = os.environ.get("WV_BACKEND")
 if backend:
     import torch
     import torch.distributed as dist
-    if backend == "nccl":
+    if backend == "nccl" and not os.environ.get("WV_NO_SET_DEVICE"):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
     from waveome_amd import parallel
@@ -58,7 +58,8 @@ if backend:
 with open(os.environ["WV_OUT"] + "." + os.environ.get("RANK", "s"), "wb") as fh:
     pickle.dump(out, fh)
 if backend:
-    dist.barrier()
+    # (a barrier on a tensor of this rank's own device: dist.barrier() under nccl would use the CURRENT device)
+    dist.all_reduce(torch.zeros(1, device=parallel.collective_device()))
     dist.destroy_process_group()
 '''
 
@@ -113,6 +114,34 @@ def test_one_rank_over_rccl_reproduces_the_single_process_results(tmp_path):
     assert got["pen"] == single["pen"]
     np.testing.assert_array_equal(got["sweep"], single["sweep"])
     assert got["search"] == single["search"] and got["best"] == single["best"]
+
+
+def test_two_ranks_over_rccl_without_set_device(tmp_path):
+    """a caller that never calls `torch.cuda.set_device` - every collective of the library, the dealer's
+    key included, must land on the rank's own GPU (`collective_device()`), not on `cuda:0` of every rank.  Needs two GPUs:
+    skipped on the one-GPU test box, there for the node the scaling run gets."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    out = str(tmp_path / "res")
+    p = _run({}, out)
+    log, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, log.decode()[-3000:]
+    port = _free_port()
+    procs = [_run({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                   "MASTER_PORT": str(port), "WV_BACKEND": "nccl", "WV_NO_SET_DEVICE": "1",
+                   "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, out) for r in range(2)]
+    for q in procs:
+        log, _ = q.communicate(timeout=600)
+        assert q.returncode == 0, log.decode()[-3000:]
+    single = pickle.load(open(out + ".s", "rb"))
+    for r in range(2):
+        got = pickle.load(open(out + f".{r}", "rb"))
+        assert got["shared_on_device"] is True
+        assert got["pen"] == single["pen"]
+        np.testing.assert_array_equal(got["sweep"], single["sweep"])
+        assert got["search"] == single["search"] and got["best"] == single["best"]
 
 
 def test_sharded_search_with_a_structure_beyond_the_session_capacities(tmp_path):
