@@ -120,9 +120,13 @@ def test_two_ranks_over_rccl_without_set_device(tmp_path):
     """a caller that never calls `torch.cuda.set_device` - every collective of the library, the dealer's
     key included, must land on the rank's own GPU (`collective_device()`), not on `cuda:0` of every rank.  Needs two GPUs:
     skipped on the one-GPU test box, there for the node the scaling run gets."""
-    import torch
+    import ctypes
 
-    if torch.cuda.device_count() < 2:
+    from waveome_amd import _lib
+
+    n = ctypes.c_int32(0)   # (through the library's own runtime: importing torch here would bring a second HIP runtime
+    _lib.check(_lib.load().wv_device_count(ctypes.byref(n)), "wv_device_count")   #  into the suite's process)
+    if n.value < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     out = str(tmp_path / "res")
     p = _run({}, out)
