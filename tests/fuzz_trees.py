@@ -3,7 +3,10 @@ tests/test_gpu_parity.py::test_random_kernel_trees_match_oracle does for ten see
 over every kernel type, random sizes (padding edges included), random parameter points, Horseshoe priors, several
 fits per call.  Not collected by pytest (no test_ prefix); run by hand on a GPU box:
 
-    python tests/fuzz_trees.py [first_seed=1000] [n_seeds=300] > profiles/rNN_fuzz_trees.txt
+    python tests/fuzz_trees.py [first_seed=1000] [n_seeds=300] [float64|float32] > profiles/rNN_fuzz_trees.txt
+
+(float32: the float32 context against the same float64 oracle with the float32 parity tolerances - loss / LML 1e-6,
+gradient 1e-4; the Gram matrix is then one float32 rounding of each entry.)
 
 Prints one line per seed and a summary; exits non-zero on a mismatch."""
 import os
@@ -67,20 +70,22 @@ def one(ctx, seed):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    ctx = Context(0)
+    dtype = sys.argv[3] if len(sys.argv) > 3 else "float64"
+    lim = (1e-12, 1e-9, 1e-6) if dtype == "float64" else (2e-7, 1e-6, 1e-4)
+    ctx = Context(0, dtype=dtype)
     worst = [0.0, 0.0, 0.0]
     bad = 0
     t0 = time.time()
     for seed in range(first, first + n):
         what, ge, le, gre = one(ctx, seed)
         flag = ""
-        if ge > 1e-12 or le > 1e-9 or gre > 1e-6 or "DEVICE" in what or "ORACLE-INF" in what:
+        if ge > lim[0] or le > lim[1] or gre > lim[2] or "DEVICE" in what or "ORACLE-INF" in what:
             flag = "  <-- MISMATCH"
             bad += 1
         worst = [max(a, b) for a, b in zip(worst, (ge, le, gre))]
         print(f"seed {seed}: {what}; gram {ge:.1e} loss {le:.1e} grad {gre:.1e}{flag}", flush=True)
-    print(f"# {n} seeds in {time.time() - t0:.0f} s: worst gram {worst[0]:.1e} (limit 1e-12), loss / LML {worst[1]:.1e} "
-          f"(1e-9), gradient {worst[2]:.1e} (1e-6); mismatches: {bad}")
+    print(f"# {dtype}: {n} seeds in {time.time() - t0:.0f} s: worst gram {worst[0]:.1e} (limit {lim[0]:g}), loss / LML {worst[1]:.1e} "
+          f"({lim[1]:g}), gradient {worst[2]:.1e} ({lim[2]:g}); mismatches: {bad}")
     ctx.close()
     return 1 if bad else 0
 

@@ -380,3 +380,40 @@ def test_f32_higher_orders_for_an_ill_conditioned_gram_matrix(tmp_path):
         err[order] = max(abs(l32 - l64), abs(f32 - f64)) / abs(l64)
     print("float32 value error by WV_F32_ORDER at cond ~ 8e5:", err)
     assert err["1"] < 1e-4 and err["2"] < 1e-6 and err["4"] < 1e-6 and max(err["2"], err["4"]) < 0.1 * err["1"]
+
+
+@pytest.mark.parametrize("seed", range(40, 52))
+def test_f32_random_kernel_trees_match_the_float64_oracle(ctx32, seed):
+    """The float32 context on seeded random Sum / Product trees over every kernel type (the generator of
+    tests/test_gpu_parity.py): frozen variances, Polynomial and Empty factors and products among them - the terms whose
+    K_y-weighted sum the trace pass cannot take from a gradient sum and evaluates explicitly (trace_kernel, KSUM).  Loss / LML
+    1e-6, gradient 1e-4 against the float64 oracle."""
+    import test_gpu_parity as T
+
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(seed)
+    kern = T._random_tree(rng, int(rng.integers(1, 4)))
+    ms = ModelSpec(kern, 4, K.GaussianLikelihood(), K.ConstantMean() if rng.random() < 0.7 else None)
+    if rng.random() < 0.6:
+        T._with_priors(ms, scale=float(rng.choice([0.1, 1.0, 10.0])))
+    if sum(len(t) for t in ms.terms) > 128 or len(ms.terms) > 64 or max(len(t) for t in ms.terms) > 4:
+        pytest.skip("beyond the limits of one device spec")
+    N = int(rng.choice([17, 64, 129, 200, 333, 400]))
+    X, Y = T._data(seed, N)
+    nb = int(rng.integers(1, 4))
+    prob = Problem(ctx32, X, Y, ms, max_batch=nb)
+    d = ms.to_dict()
+    U = np.stack([ms.unconstrain() + 0.3 * rng.normal(size=ms.n_trainable) for _ in range(nb)])
+    cols = rng.integers(0, Y.shape[1], nb).astype(np.int32)
+    loss, grad, st = prob.value_grad(cols, U)
+    lml, st2 = prob.lml(cols, np.stack([ms.constrain(u) for u in U]))
+    prob.close()
+    for b in range(nb):
+        fo, go = o.objective(d, U[b], X, Y[:, cols[b]])
+        if not np.isfinite(fo):
+            continue
+        assert st[b] == 0 and st2[b] == 0
+        assert abs(loss[b] - fo) <= 1e-6 * max(1.0, abs(fo)), (seed, b, loss[b], fo)
+        assert abs(lml[b] - o.lml(d, ms.constrain(U[b]), X, Y[:, cols[b]])) <= 1e-6 * max(1.0, abs(fo))
+        assert np.max(np.abs(grad[b] - go)) <= 1e-4 * max(1.0, np.max(np.abs(go))), (seed, b)
