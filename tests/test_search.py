@@ -165,6 +165,22 @@ def test_search_prune_inserts_only_improvements():
     assert len(kids) == 1
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _one_blas_thread():
+    """The oracle fits of this file are on 48-row matrices, where threaded OpenBLAS buys nothing - and in the 8-CPU build
+    container a threaded LAPACK call in them (dpotri, 48 x 48) was seen to spin for minutes once in a few runs of the whole
+    CPU suite (always in this file, which runs after the tests that start gloo rank processes).  One BLAS thread here
+    makes the suite's time deterministic; the other files keep the thread count their chaotic-path tolerances were
+    written with."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=1):
+        yield
+
+
 class OracleScorer:
     """CPU stand-in for kernel_search.GpuScorer: the same scoring rule on SciPy fits of the oracle."""
 
