@@ -19,8 +19,9 @@ from oracle.closed_forms import (closed_form, closed_form_lin_poly, closed_form_
                                  headline_closed_form, low_rank_lml, periodic_features, se_features)
 
 
-def main_headline(N):
-    """The headline structure itself, one fit, at a size far beyond the bench's: device LML against the closed form."""
+def main_headline(N, dtype="float64"):
+    """The headline structure itself, one fit, at a size far beyond the bench's: device LML against the closed form
+    (`... N headline float32`: on a float32 context, against the float32 parity tolerance 1e-6)."""
     import bench
 
     saved = bench.N_HEAD
@@ -30,7 +31,8 @@ def main_headline(N):
     finally:
         bench.N_HEAD = saved
     ms = bench.headline_spec()
-    ctx = Context(0)
+    ctx = Context(0, dtype=dtype)
+    tol = 1e-9 if dtype == "float64" else 1e-6
     prob = Problem(ctx, X, Y.T, ms, max_batch=1)
     t0 = time.time()
     want = headline_closed_form(ms.theta(), X, Y[0])
@@ -44,16 +46,16 @@ def main_headline(N):
     prob.close()
     ctx.close()
     rel = max(abs(lml[0] - want), abs(-f[0] - want)) / abs(want)
-    print(f"headline structure, N = {N}: closed form {want:.6f} ({tc:.1f} s on the CPU), device value-only {lml[0]:.6f} ({t1:.2f} s), "
+    print(f"headline structure, {dtype}, N = {N}: closed form {want:.6f} ({tc:.1f} s on the CPU), device value-only {lml[0]:.6f} ({t1:.2f} s), "
           f"value + gradient {-f[0]:.6f} ({t2:.2f} s = {N ** 3 / t2 / 1e12:.1f} TFLOP/s on N^3); worst rel {rel:.1e}, status {st[0]} {st2[0]}")
-    print("# ok" if rel < 1e-9 else "# MISMATCH")
-    return 0 if rel < 1e-9 else 1
+    print("# ok" if rel < tol else "# MISMATCH")
+    return 0 if rel < tol else 1
 
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
     if len(sys.argv) > 2 and sys.argv[2] == "headline":
-        return main_headline(N)
+        return main_headline(N, sys.argv[3] if len(sys.argv) > 3 else "float64")
     rng = np.random.default_rng(1)
     lab = rng.integers(0, 2, N).astype(float)
     X = np.column_stack([rng.normal(size=N), lab])
