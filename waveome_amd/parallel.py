@@ -281,8 +281,10 @@ def set_deal_store(store) -> None:
 
 
 def _group_token():
+    """The current default process group OBJECT (kept alive by the cache entry, so that a later group can never be mistaken
+    for it through a recycled id), or None."""
     dist = _dist()
-    return id(dist.group.WORLD) if dist.is_initialized() else None
+    return dist.group.WORLD if dist.is_initialized() else None
 
 
 def deal_store():
@@ -293,7 +295,7 @@ def deal_store():
     the process group's own rendezvous store is private to torch (`distributed_c10d._get_default_store`) and is not
     touched."""
     global _DEAL_STORE
-    if _DEAL_STORE is not None and _DEAL_STORE[1] == _group_token():
+    if _DEAL_STORE is not None and _DEAL_STORE[1] is _group_token():
         return _DEAL_STORE[0]
     import datetime
     import os
