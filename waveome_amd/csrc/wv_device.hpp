@@ -94,6 +94,7 @@ struct GemmArgsT {
   int32_t rot_tri;     // rotate the launch order of lower-only products per matrix
   int32_t xskip;       // WV_GEMM_DBG: parts of the kernel switched off for timing (results become wrong)
   int32_t tri_order;   // WV_TRI_ORDER=1: strictly-lower tiles of M'M / the trailing update in 4 x 4 super-blocks (L2 experiment)
+  int32_t stagger, stagger_mode;  // WV_GEMM_STAGGER=<cycles>[,mode]: some workgroups of a launch's first wave wait before their tile
 #endif
   // Block structure (wv_spec.hpp, block_column): when `spans` is set, a matrix whose structure (slot_spec -> spec_span)
   // has a span table only walks the k that can meet a non-zero in both operands: with (sp_r0, sp_c0, sp_k0) the
