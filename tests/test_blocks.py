@@ -271,6 +271,54 @@ def test_block_and_dense_structures_share_a_batch():
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_decoupled_recursion_gives_way_when_a_dense_structure_is_added():
+    """Round 5: while EVERY structure of a problem is block-diagonal with units ending on the 128-row node boundaries, the
+    recursion launches no S / update / T / M21 for the decoupled nodes (M21 stays the zero block it was created as) and
+    factors runs of independent 128-nodes in one launch.  The moment a dense structure joins the problem
+    (`wv_problem_add_spec`, as the kernel search does) every product runs again, for good - and the fits of the
+    block-diagonal structure before and after the switch, and beside the dense one, are the same bits as on a problem of
+    their own."""
+    from waveome_amd.engine import Context, Problem, lbfgs_opts
+
+    X, Y = _longitudinal(5, 8, 128)                      # 1024 rows: eight units, one per 128-node pair boundary
+    u = lambda: K.Categorical(active_dims=[2])
+    block = ModelSpec(K.Sum([u(), K.Product([u(), K.SquaredExponential(active_dims=[0])])]), 3, K.GaussianLikelihood(),
+                      K.ConstantMean())
+    dense = ModelSpec(K.Sum([K.SquaredExponential(active_dims=[0]), u()]), 3, K.GaussianLikelihood(), K.ConstantMean())
+    assert block.block_column() == 2 and dense.block_column() == -1
+    ctx = Context(0)
+    opts = lbfgs_opts(maxiter=12)
+    caps = {"max_specs": 2, "max_params": 8, "max_feat": 4, "max_factors": 4, "max_red": 8}
+    width = max(block.n_trainable, dense.n_trainable)
+    cols = np.array([0, 1, 2], dtype=np.int32)
+
+    def u0(spec, n):
+        U = np.zeros((n, width))
+        U[:, :spec.n_trainable] = spec.unconstrain()
+        return U
+
+    alone = Problem(ctx, X, Y, [block], max_batch=3, capacity=caps)          # decoupled throughout
+    ref_block = alone.fit_multi(cols, np.zeros(3, dtype=np.int32), u0(block, 3), opts)
+    alone.close()
+    both = Problem(ctx, X, Y, [block, dense], max_batch=3, capacity=caps)    # never decoupled
+    ref_dense = both.fit_multi(cols, np.ones(3, dtype=np.int32), u0(dense, 3), opts)
+    both.close()
+
+    grow = Problem(ctx, X, Y, [block], max_batch=3, capacity=caps)
+    before = grow.fit_multi(cols, np.zeros(3, dtype=np.int32), u0(block, 3), opts)        # decoupled schedule
+    assert grow.add_spec(dense) == 1                                                      # ... no longer
+    mixed = grow.fit_multi(np.array([0, 0, 1, 1, 2, 2], dtype=np.int32), np.array([0, 1, 0, 1, 0, 1], dtype=np.int32),
+                           np.stack([u0(block, 1)[0], u0(dense, 1)[0]] * 3), opts)
+    grow.close()
+    ctx.close()
+    for key in ("loss", "lml", "nit", "nfev", "status"):
+        np.testing.assert_array_equal(before[key], ref_block[key], err_msg=key)
+        np.testing.assert_array_equal(mixed[key][0::2], ref_block[key], err_msg=key)
+        np.testing.assert_array_equal(mixed[key][1::2], ref_dense[key], err_msg=key)
+    np.testing.assert_array_equal(mixed["u"][0::2, :block.n_trainable], ref_block["u"][:, :block.n_trainable])
+
+
 def test_shared_inputs_sorted_by_keeps_rows_together():
     from waveome_amd.parallel import SharedInputs
 
