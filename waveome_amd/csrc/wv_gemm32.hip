@@ -38,20 +38,28 @@ struct Tile {
   static constexpr int NLOAD = ROWS * KC / 4 / 256;  // float4 loads per thread per chunk (= 4)
   __device__ static inline int at(int row, int k) { return KCONTIG ? row * LD + k : k * LD + row; }
 
-  __device__ static inline void gload(f4 (&reg)[NLOAD], const float* __restrict__ base, int ld, int row0,
-                                      int nrows, int k0, int tid) {
+  // A chunk's NLOAD loads of one thread are "uniform piece base + ONE per-thread byte offset": piece i of a K-contiguous
+  // operand is its rows 32 i .. 32 i + 31, of a K-strided one its k rows 8 i .. 8 i + 7.  The offset is computed once per
+  // tile; the piece bases are scalar arithmetic per chunk - no per-lane 64-bit addresses, masks or zero fill (with the
+  // float64 partial sums of the accumulator flush this kernel sits at its 256-register limit: the per-chunk addresses
+  // were what spilled, and a reload of a spill waits on the prefetch in flight).  Rows past the operand's extent (extents
+  // are multiples of 64: launch_gemm checks) are redirected to valid rows: they only feed C elements the epilogue masks.
+  __device__ static inline uint32_t goffset(int ld, int row0, int nrows, int tid) {
+    if (KCONTIG) return ((uint32_t)(tid >> 3) * (uint32_t)ld + 4u * (tid & 7)) * 4u;
+    return ((uint32_t)(tid >> 5) * (uint32_t)ld + (uint32_t)min(4 * (tid & 31), nrows - 4 - row0)) * 4u;
+  }
+  __device__ static inline void gload(f4 (&reg)[NLOAD], const float* __restrict__ base, int ld, int row0, int nrows,
+                                      int k0, uint32_t off) {
+    // (buffer loads: the descriptor - four scalar registers - holds the chunk's 64-bit base, the piece offset is the
+    //  instruction's scalar offset, the lane's part its 32-bit vector offset)
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const float* cbase = base + (KCONTIG ? (int64_t)row0 * ld + k0 : (int64_t)k0 * ld + row0);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cbase), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int q = tid + 256 * i;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (KCONTIG) {
-        const int row = q >> 3, kp = q & 7;
-        if (row0 + row < nrows) v = *reinterpret_cast<const f4*>(base + (int64_t)(row0 + row) * ld + k0 + 4 * kp);
-      } else {
-        const int k = q >> 5, rp = q & 31;
-        if (row0 + 4 * rp < nrows) v = *reinterpret_cast<const f4*>(base + (int64_t)(k0 + k) * ld + row0 + 4 * rp);
-      }
-      reg[i] = v;
+      const int piece = KCONTIG ? (row0 + 32 * i < nrows ? 32 * i : 0) : 8 * i;  // (uniform)
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, piece * ld * 4, 0);
+      reg[i] = __builtin_bit_cast(f4, v);
     }
   }
   __device__ static inline void sstore(float* __restrict__ s, const f4 (&reg)[NLOAD], int tid) {
@@ -197,9 +205,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
   const int nchunk = (ke - kb + KC - 1) / KC;
   const int kstep = g.klo_mode ? -KC : KC;  // tiles trimmed from below walk K downwards from the common end
   kb = g.klo_mode ? ke - KC : kb;
+  const uint32_t offa = TA::goffset(g.lda, m0, g.M, tid), offb = TB::goffset(g.ldb, n0, g.N, tid);
   if (nchunk > 0) {
-    TA::gload(ra, A, g.lda, m0, g.M, kb, tid);
-    TB::gload(rb, B, g.ldb, n0, g.N, kb, tid);
+    TA::gload(ra, A, g.lda, m0, g.M, kb, offa);
+    TB::gload(rb, B, g.ldb, n0, g.N, kb, offb);
     TA::sstore(sA[0], ra, tid);
     TB::sstore(sB[0], rb, tid);
   }
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunk) {
-      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, tid);
-      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, tid);
+      TA::gload(ra, A, g.lda, m0, g.M, kb + (c + 1) * kstep, offa);
+      TB::gload(rb, B, g.ldb, n0, g.N, kb + (c + 1) * kstep, offb);
     }
     const float* __restrict__ a_s = sA[cur];
     const float* __restrict__ b_s = sB[cur];
@@ -306,6 +315,10 @@ void launch_gemm(hipStream_t st, const GemmArgsF& a_in, bool a_kc, bool b_kc, in
     return;
   }
   if (a.M <= 0 || a.N <= 0 || a.nbatch <= 0) return;
+  if ((a.M | a.N) & 63) {  // (the kernel's operand loads redirect whole 32-row pieces past the extent)
+    fail_launch("launch_gemm(float32): extents must be multiples of 64");
+    return;
+  }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   int tiles = a.tiles_m * a.tiles_n;
