@@ -47,19 +47,23 @@ def _kernel():
 
 @pytest.mark.parametrize("a_kc", [True, False])
 @pytest.mark.parametrize("nb", [3, 9])  # 9: the batch -> XCD mapping of launches with >= 8 matrices
-def test_f32_mfma_gemm(ctx32, a_kc, nb):
+# partial row and column tiles (the operand loads redirect whole 32-row pieces past the extent: their products land in
+# masked C elements only), one tile smaller than the tiling, and a contraction of 34 chunks (two float64 flushes + a rest)
+@pytest.mark.parametrize("shape", [(256, 192, 128), (192, 320, 64), (64, 64, 64), (320, 64, 1088)])
+def test_f32_mfma_gemm(ctx32, a_kc, nb, shape):
     rng = np.random.default_rng(1)
-    M, N, Kd = 256, 192, 128
+    M, N, Kd = shape
     A = rng.normal(size=(nb, M, Kd) if a_kc else (nb, Kd, M)).astype(np.float32)
     B = rng.normal(size=(nb, Kd, N)).astype(np.float32)
     C0 = rng.normal(size=(nb, M, N)).astype(np.float32)
     Am = A if a_kc else np.swapaxes(A, 1, 2)
     want = -0.5 * np.einsum("bmk,bkn->bmn", Am.astype(np.float64), B.astype(np.float64)) + 2.0 * C0
     got = ctx32.dbg_gemm(A, B, C0, a_kcontig=a_kc, b_kcontig=False, alpha=-0.5, beta=2.0)
-    # float32 accumulation over K = 128 terms of size ~1: a few 1e-6 relative to sqrt(K)
-    assert np.max(np.abs(got - want)) < 2e-4
+    # float32 accumulation over <= 512 terms of size ~1 between float64 flushes: a few 1e-6 relative to sqrt(K)
+    tol = 2e-4 * max(1.0, np.sqrt(Kd / 128.0))
+    assert np.max(np.abs(got - want)) < tol
     got0 = ctx32.dbg_gemm(A, B, np.zeros_like(C0), a_kcontig=a_kc, b_kcontig=False)
-    assert np.max(np.abs(got0 - np.einsum("bmk,bkn->bmn", Am.astype(np.float64), B.astype(np.float64)))) < 2e-4
+    assert np.max(np.abs(got0 - np.einsum("bmk,bkn->bmn", Am.astype(np.float64), B.astype(np.float64)))) < tol
 
 
 def test_f32_factor_inverse_stages(ctx32, ctx64):
