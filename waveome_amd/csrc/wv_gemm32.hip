@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgsF g) {
   } else {
     tm = tile / g.tiles_n;
     tn = tile % g.tiles_n;
-    // column-dependent contraction lengths: Latin-square skew (see wv_gemm.hip)
-    if (g.khi_mode == 2 || g.klo_mode == 2) tn = (tn + tm) % g.tiles_n;
+    if (g.khi_mode == 2 || g.klo_mode == 2) {  // column-dependent contraction lengths: column-major (see wv_gemm.hip)
+      tn = tile / g.tiles_m;
+      tm = tile % g.tiles_m;
+    }
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
