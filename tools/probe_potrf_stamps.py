@@ -24,8 +24,8 @@ lib = ctypes.CDLL(os.environ["WAVEOME_AMD_LIB"])
 out = (ctypes.c_ulonglong * 32)()
 assert lib.wv_dbg_stamps(out) == 0
 s = np.array(list(out), dtype=np.int64)
-names = {1: "load A11, clear X", 2: "factor64 (A11)", 3: "stage L, log-det", 4: "invert64 (M11)", 5: "write M11 / M11'",
-         6: "S = A21 M11' (+ staging)", 7: "A22 -= S S', T2 = S M11", 8: "clear X, factor64 (Schur)", 9: "stage L, log-det",
+names = {1: "load A11", 2: "stage + factor64c (A11) + clear X", 3: "4x4 inverses, log-det", 4: "invert64 (M11)", 5: "write M11 / M11'",
+         6: "S = A21 M11' (+ staging)", 7: "A22 -= S S', T2 = S M11", 8: "stage + factor64c (Schur) + clear X", 9: "4x4 inverses, log-det",
          10: "invert64 (M22)", 11: "write M22 / M22'", 12: "M21 = -M22 T2, stores"}
 tot = s[12] - s[0]
 print(f"potrf128, one workgroup, last node of an evaluation at N = {N}: {tot} shader-clock ticks")
@@ -33,9 +33,4 @@ for i in range(1, 13):
     print(f"  {names[i]:32s} {s[i] - s[i - 1]:8d}  {100.0 * (s[i] - s[i - 1]) / tot:5.1f} %")
 inv = [s[16] - s[9], s[17] - s[16], s[18] - s[17], s[19] - s[18], s[10] - s[19]]
 print("  inside the second invert64: 4x4 blocks %d, level 4: %d, 8: %d, 16: %d, 32: %d" % tuple(inv))
-print("  one step of factor64b (Schur block, columns 16-19) seen by thread (15, 15): wait for the 4 x 4 diagonal factor %d, "
-      "wait for the panel %d, own rank-4 update %d  (next step starts %d later)" % (s[21] - s[20], s[22] - s[21], s[23] - s[22], s[24] - s[23]))
-print("    its diagonal thread (4, 4): the 4 x 4 factor and the write of its ten numbers %d" % (s[14] - s[13]))
-print("    a panel thread (15, 4): barrier to first use of the factor (LDS reads issued) %d, the four row solves and their "
-      "LDS writes issued %d, to the far side of the next barrier %d" % (s[26] - s[25], s[27] - s[26], s[28] - s[27]))
 prob.close()

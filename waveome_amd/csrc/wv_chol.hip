@@ -86,9 +86,10 @@ void launch_potrf_diag(Problem& p, hipStream_t st, int slot0, int nb, int j0) {
 //
 // With one fit in flight the sixteen leaves of an N = 2048 evaluation are a dependent chain, so this kernel is
 // built for the latency of ONE workgroup (round 2; shader-clock stamps of the phases: tools/probe_potrf_stamps.py):
-//   * factor64b: 16 x 16 threads x (4 x 4) registers, FOUR columns per step - the diagonal thread factors its 4 x 4
-//     block in registers, the panel threads solve against it, everyone below updates: two barriers per four
-//     columns instead of one per column; the 4 x 4 inverses are formed afterwards, sixteen threads at once;
+//   * factor64c (round 5): a row per lane in every wave, the columns dealt to the four waves in blocks of four; the
+//     owner's chain pivot -> rsqrt -> scale -> next pivot stays in its registers (v_readlane), one barrier and one
+//     LDS round trip per four columns; the 4 x 4 inverses are formed afterwards, sixteen threads at once
+//     (rounds 2 - 4: factor64b, 16 x 16 threads x (4 x 4) registers, two barriers and three round trips per step);
 //   * the 64^3 products and the two upper levels of the triangular inversion run on v_mfma_f64_4x4x4_4b out of LDS
 //     (wave_mma; the lane maps are those of wv_gemm.hip) instead of fp64 VALU dot products.
 // ---------------------------------------------------------------------------------------
@@ -98,20 +99,8 @@ __device__ unsigned long long wv_stamps[32];
   do {                                                                                    \
     if (blockIdx.x == 0 && threadIdx.x == 0) wv_stamps[i] = __builtin_readcyclecounter(); \
   } while (0)
-// thread 255 = block (15, 15): active in every rank-4 update, so its waits show the other phases' lengths
-#define WV_STAMP_LAST(i)                                                                    \
-  do {                                                                                      \
-    if (blockIdx.x == 0 && threadIdx.x == 255) wv_stamps[i] = __builtin_readcyclecounter(); \
-  } while (0)
-// thread 244 = block (15, 4): a panel thread of step 4; thread 68 = block (4, 4): that step's diagonal thread
-#define WV_STAMP_T(i, t)                                                                    \
-  do {                                                                                      \
-    if (blockIdx.x == 0 && threadIdx.x == (t)) wv_stamps[i] = __builtin_readcyclecounter(); \
-  } while (0)
 #else
 #define WV_STAMP(i)
-#define WV_STAMP_LAST(i)
-#define WV_STAMP_T(i, t)
 #endif
 
 // acc[ia][jc][r] += sum over k in [kbeg, kend) of A(16 ia + 4 blk + e, k) * B(k, 16 jc + 4 ((blk + r0 + r) & 3) + e)
@@ -167,93 +156,134 @@ __device__ inline void mma_store(const double (&acc)[NA][NC][NR], R* __restrict_
       for (int r = 0; r < NR; ++r) C[mma_row(ia, lane) * ldc + mma_col(jc, r, r0, lane)] = (R)(sign * acc[ia][jc][r]);
 }
 
-// Blocked register-tiled Cholesky of a 64 x 64 block held as 4 x 4 per thread (16 x 16 threads), four columns per
-// step.  dinfo[jb][0..9]: diagonal block jb's sub-diagonal entries and reciprocal pivots (kept for all sixteen
-// blocks: diag_inverses turns them into the 4 x 4 inverses afterwards); pbuf[64][4]: the solved panel.
-// Returns "this thread saw a non-positive / NaN pivot".
-constexpr int DINFO = 10;
-template <typename R>
-__device__ inline bool factor64b(R (&a)[4][4], R* __restrict__ dinfo, R* __restrict__ pbuf, int ty, int tx) {
-  bool anybad = false;
-  for (int jb = 0; jb < 16; ++jb) {
-    R* dbuf = dinfo + DINFO * jb;
-    if (jb == 4) WV_STAMP_LAST(20);
-    if (jb == 4) WV_STAMP_T(13, 68);
-    if (ty == jb && tx == jb) {
-      // 4 x 4 factor of the diagonal block: the critical path of the whole leaf (four dependent rsqrt per step).  (An
-      // LDL' recurrence on v_rcp_f64 reciprocals with the four rsqrt hanging off the chain measured 14 % SLOWER.)
-      R inv[4];
+// ---------------------------------------------------------------------------------------
+// factor64c: the 64 x 64 Cholesky factor by the four waves of the workgroup, a ROW per lane in every wave, the COLUMNS
+// dealt to the waves in blocks of four (wave w owns column blocks w, w + 4, w + 8, w + 12: sixteen doubles per lane),
+// every register index a compile-time constant.  Step jb: the owner factors its four columns in registers - pivot out of
+// lane j by v_readlane, scale, the block's later columns updated with lane j + 1..'s entries by v_readlane again: the
+// chain pivot -> rsqrt -> scale -> next pivot never leaves the wave - and publishes them in LDS (all sixteen panels keep
+// their own place: no buffer is ever reused); one barrier; every wave then subtracts the panel from the blocks it owns
+// (own-row values + uniform-address broadcast reads).  The NEXT owner updates only the block it is about to factor and
+// catches up on its other blocks after its own chain.  factor64b's step went through two barriers and three LDS round
+// trips with the 4 x 4 diagonal factor, the panel solve and the rank-4 update in sequence (2 500 cycles per four columns,
+// tools/probe_potrf_stamps.py); a single wave holding whole rows (factor64w, tried first) is bound by its own issue rate
+// (6 200 instructions, 35 k cycles: no gain).
+//   Lb: in = the block (lower triangle used), out = L with the upper triangle zeroed;  rinv[64]: reciprocal pivots;
+//   Pan: 4096 doubles of scratch ([column][row]).  Called by all 256 threads; returns "this wave saw a non-positive / NaN pivot".
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_f64;  // (LDS pointers as such: constant offsets fold into ds_* offset fields)
+__device__ inline double lane_bcast(double v, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// a[q][t] -= sum_c panel(P)[row][c] * panel(P)[4 B + t][c] for this wave's block q (B = 4 q + W)
+template <int W, int P, int Q>
+__device__ __forceinline__ void factor64c_apply(double (&a)[4][4], const double (&own)[4], const lds_f64* __restrict__ Pan) {
+  constexpr int B = 4 * Q + W;
+  double bc[4][4];  // (all sixteen broadcast values in flight before the first product: one LDS latency, not eight)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        R piv = a[c][c];
-        const bool ok = piv > R(0);  // false for NaN as well
-        if (!ok) { piv = 1; anybad = true; }
-        inv[c] = rsq(piv);
-        a[c][c] = piv * inv[c];
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = c + 1; r < 4; ++r) a[r][c] *= inv[c];
+    for (int t = 0; t < 4; ++t) bc[c][t] = Pan[(4 * P + c) * NB + 4 * B + t];
+  __builtin_amdgcn_sched_barrier(0);  // (hipcc's scheduler would keep two reads in flight and wait on each pair)
 #pragma unroll
-        for (int c2 = c + 1; c2 < 4; ++c2)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int r = c2; r < 4; ++r) a[r][c2] -= a[r][c] * a[c2][c];
-      }
-      dbuf[0] = a[1][0]; dbuf[1] = a[2][0]; dbuf[2] = a[3][0]; dbuf[3] = a[2][1]; dbuf[4] = a[3][1]; dbuf[5] = a[3][2];
-      dbuf[6] = inv[0]; dbuf[7] = inv[1]; dbuf[8] = inv[2]; dbuf[9] = inv[3];
-      if (jb == 4) WV_STAMP_T(14, 68);
+    for (int t = 0; t < 4; ++t) a[Q][t] -= own[c] * bc[c][t];
+}
+// panel P subtracted from this wave's blocks FROM..3 (those that lie behind block AFTER)
+template <int W, int P, int AFTER, bool ONLY_NEXT>
+__device__ __forceinline__ void factor64c_update(double (&a)[4][4], const lds_f64* __restrict__ Pan, int lane) {
+  constexpr bool any = 4 * 3 + W > AFTER;
+  if constexpr (any) {
+    double own[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) own[c] = Pan[(4 * P + c) * NB + lane];
+    if constexpr (ONLY_NEXT) {
+      factor64c_apply<W, P, (AFTER + 1) / 4>(a, own, Pan);  // (AFTER + 1 is this wave's block)
+    } else {
+      if constexpr (4 * 0 + W > AFTER) factor64c_apply<W, P, 0>(a, own, Pan);
+      if constexpr (4 * 1 + W > AFTER) factor64c_apply<W, P, 1>(a, own, Pan);
+      if constexpr (4 * 2 + W > AFTER) factor64c_apply<W, P, 2>(a, own, Pan);
+      if constexpr (4 * 3 + W > AFTER) factor64c_apply<W, P, 3>(a, own, Pan);
     }
-    __syncthreads();
-    if (jb == 4) WV_STAMP_LAST(21);
-    if (jb == 4) WV_STAMP_T(25, 244);
-    if (tx == jb && ty > jb) {  // panel: rows of this thread times inv(L_jj)'
-      const R l10 = dbuf[0], l20 = dbuf[1], l30 = dbuf[2], l21 = dbuf[3], l31 = dbuf[4], l32 = dbuf[5];
-      const R i0 = dbuf[6], i1 = dbuf[7], i2 = dbuf[8], i3 = dbuf[9];
-      if (jb == 4) WV_STAMP_T(26, 244);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const R x0 = a[r][0] * i0;
-        const R x1 = (a[r][1] - x0 * l10) * i1;
-        const R x2 = (a[r][2] - x0 * l20 - x1 * l21) * i2;
-        const R x3 = (a[r][3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-        a[r][0] = x0; a[r][1] = x1; a[r][2] = x2; a[r][3] = x3;
-        R* pr = pbuf + (4 * ty + r) * 4;
-        pr[0] = x0; pr[1] = x1; pr[2] = x2; pr[3] = x3;
-      }
-      if (jb == 4) WV_STAMP_T(27, 244);
-    }
-    __syncthreads();
-    if (jb == 4) WV_STAMP_LAST(22);
-    if (jb == 4) WV_STAMP_T(28, 244);
-    if (tx > jb && ty >= tx) {
-      R lr[4][4], lc[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          lr[r][k] = pbuf[(4 * ty + r) * 4 + k];
-          lc[r][k] = pbuf[(4 * tx + r) * 4 + k];
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[r][c] -= lr[r][k] * lc[c][k];
-    }
-    if (jb == 4) WV_STAMP_LAST(23);
-    if (jb == 5) WV_STAMP_LAST(24);   // (top of the next step)
   }
+}
+template <int W, int JB>
+__device__ __forceinline__ void factor64c_step(double (&a)[4][4], lds_f64* __restrict__ Pan, lds_f64* __restrict__ rinv,
+                                               int lane, bool& anybad) {
+  constexpr int Q = JB / 4;
+  if constexpr (JB % 4 == W) {  // the owner: four columns in registers
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int J = 4 * JB + c;
+      double piv = lane_bcast(a[Q][c], J);
+      const bool ok = piv > 0.0;  // false for NaN as well
+      piv = ok ? piv : 1.0;
+      anybad |= !ok;
+      const double ri = rsq(piv);
+      const double lj = (lane == J) ? piv * ri : a[Q][c] * ri;
+      a[Q][c] = lj;
+      rinv[J] = ri;  // (the same value from every lane)
+#pragma unroll
+      for (int c2 = c + 1; c2 < 4; ++c2) a[Q][c2] -= lj * lane_bcast(lj, 4 * JB + c2);
+      Pan[J * NB + lane] = lj;
+    }
+  }
+  __syncthreads();  // panel JB is published
+  if constexpr (JB < 15) {
+    if constexpr (JB % 4 == W) {
+      // the owner catches up: the panel before its own (deferred while it was the next owner), then its own
+      if constexpr (JB >= 1) factor64c_update<W, JB - 1, JB, false>(a, Pan, lane);
+      factor64c_update<W, JB, JB, false>(a, Pan, lane);
+    } else if constexpr ((JB + 1) % 4 == W) {
+      factor64c_update<W, JB, JB, true>(a, Pan, lane);  // the next owner: only the block it factors next
+    } else {
+      factor64c_update<W, JB, JB, false>(a, Pan, lane);
+    }
+    factor64c_step<W, JB + 1>(a, Pan, rinv, lane, anybad);
+  }
+}
+template <int W>
+__device__ __forceinline__ bool factor64c_wave(lds_f64* __restrict__ Lb, lds_f64* __restrict__ Pan,
+                                               lds_f64* __restrict__ rinv, int lane) {
+  double a[4][4];  // a[q][c] = column 4 (4 q + W) + c of row `lane`
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[q][c] = Lb[lane * DS + 4 * (4 * q + W) + c];
+  bool anybad = false;
+  factor64c_step<W, 0>(a, Pan, rinv, lane, anybad);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 4 * (4 * q + W) + c;
+      Lb[lane * DS + col] = (col <= lane) ? a[q][c] : 0.0;
+    }
   return anybad;
 }
+__device__ __noinline__ bool factor64c(lds_f64* __restrict__ Lb, lds_f64* __restrict__ Pan, lds_f64* __restrict__ rinv,
+                                       int tid) {
+  const int lane = tid & 63;
+  switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+    case 0: return factor64c_wave<0>(Lb, Pan, rinv, lane);
+    case 1: return factor64c_wave<1>(Lb, Pan, rinv, lane);
+    case 2: return factor64c_wave<2>(Lb, Pan, rinv, lane);
+    default: return factor64c_wave<3>(Lb, Pan, rinv, lane);
+  }
+}
 
-// The sixteen 4 x 4 diagonal blocks of X = L^-1 from factor64b's dinfo (one thread per block; X is zero elsewhere).
-// The caller puts a barrier between factor64b and this, and another before X is read.
+// diag_inverses for factor64c: the 4 x 4 diagonal blocks of X = L^-1 from L itself and the reciprocal pivots.
 template <typename R>
-__device__ inline void diag_inverses(const R* __restrict__ dinfo, R* __restrict__ X, int tid) {
+__device__ inline void diag_inverses_L(const R* __restrict__ L, const R* __restrict__ rinv, R* __restrict__ X, int tid) {
   if ((tid & 15) == 0) {  // (four threads in each wave)
     const int jb = tid >> 4;
-    const R* d = dinfo + DINFO * jb;
-    const R l10 = d[0], l20 = d[1], l30 = d[2], l21 = d[3], l31 = d[4], l32 = d[5];
-    const R i0 = d[6], i1 = d[7], i2 = d[8], i3 = d[9];
+    const R* d = L + (4 * jb) * DS + 4 * jb;
+    const R l10 = d[DS], l20 = d[2 * DS], l30 = d[3 * DS], l21 = d[2 * DS + 1], l31 = d[3 * DS + 1], l32 = d[3 * DS + 2];
+    const R i0 = rinv[4 * jb], i1 = rinv[4 * jb + 1], i2 = rinv[4 * jb + 2], i3 = rinv[4 * jb + 3];
     const R x10 = -i1 * (l10 * i0);
     const R x21 = -i2 * (l21 * i1);
     const R x32 = -i3 * (l32 * i2);
@@ -326,8 +356,7 @@ __global__ __launch_bounds__(256, 2) void potrf_diag_kernel(R* __restrict__ Kall
   __shared__ W L[NB * DS];
   __shared__ W X[NB * DS];
   __shared__ W T[INV_SCRATCH];
-  __shared__ W pbuf[NB * 4];
-  __shared__ W dinfo[16 * DINFO];
+  __shared__ W rinv[NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
   R* K = Kall + (int64_t)b * Npad * Npad + (int64_t)j0 * Npad + j0;
@@ -342,23 +371,25 @@ __global__ __launch_bounds__(256, 2) void potrf_diag_kernel(R* __restrict__ Kall
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[r][c] = (W)v[c];
   }
+  // stage the block, factor it in place (factor64c: panels in X), clear X
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = a[r][c];
+  __syncthreads();
+  if (factor64c((lds_f64*)L, (lds_f64*)X, (lds_f64*)rinv, tid)) bad = 1;  // (same value from every writer)
+  __syncthreads();
   for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
-  const bool anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
-  // L to LDS (upper part zeroed) and back to HBM
+  // L (upper part zeroed by factor64c) back to HBM
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     R v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = 4 * ty + r, jc = 4 * tx + c;
-      const W l = (jc <= i) ? a[r][c] : W(0);
-      L[i * DS + jc] = l;
-      v[c] = (R)l;
-    }
+    for (int c = 0; c < 4; ++c) v[c] = (R)L[(4 * ty + r) * DS + 4 * tx + c];
     st4(K + (int64_t)(4 * ty + r) * Npad + 4 * tx, v);
   }
-  if (anybad) bad = 1;  // (same value from every writer)
-  diag_inverses<W>(dinfo, X, tid);
+  __syncthreads();
+  diag_inverses_L<W>(L, rinv, X, tid);
   __syncthreads();
   if (tid < 64) {
     double v = log((double)L[tid * DS + tid]);
@@ -400,8 +431,7 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   __shared__ W L[NB * DS];
   __shared__ W X[NB * DS];
   __shared__ W T[INV_SCRATCH];
-  __shared__ W pbuf[NB * 4];
-  __shared__ W dinfo[16 * DINFO];
+  __shared__ W rinv[NB];
   __shared__ int bad;
   const int b = slot0 + blockIdx.x;
   o += 2 * NB * (int)blockIdx.y;   // (a run of independent 128-nodes in one launch: block structures, fi_node)
@@ -414,16 +444,19 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   const int64_t o1 = o, o2 = o + NB;
   if (tid == 0) bad = 0;
 
-  auto stage_L_and_logdet = [&](W (&a)[4][4], bool anybad, int blk) {  // L -> LDS (upper zeroed), log-det partial
+  // factor the block staged in L (factor64c, its panels in X), clear X, 4 x 4 inverses, log-det partial
+  auto factor_L_and_logdet = [&](W (&a)[4][4], int blk) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = 4 * ty + r, jc = 4 * tx + c;
-        L[i * DS + jc] = (jc <= i) ? a[r][c] : W(0);
-      }
-    if (anybad) bad = 1;  // (same value from every writer)
-    diag_inverses<W>(dinfo, X, tid);  // (dinfo is complete: factor64b's last barrier is behind every thread)
+      for (int c = 0; c < 4; ++c) L[(4 * ty + r) * DS + 4 * tx + c] = a[r][c];
+    __syncthreads();
+    if (factor64c((lds_f64*)L, (lds_f64*)X, (lds_f64*)rinv, tid)) bad = 1;  // (same value from every writer)
+    __syncthreads();
+    for (int q = tid; q < NB * DS; q += 256) X[q] = 0;  // (the panels lived in X)
+    __syncthreads();
+    if (blk & 1) WV_STAMP(8); else WV_STAMP(2);
+    diag_inverses_L<W>(L, rinv, X, tid);
     __syncthreads();
     if (tid < 64) {
       double v = log((double)L[tid * DS + tid]);
@@ -457,11 +490,8 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   W a[4][4];
   WV_STAMP(0);
   load_block(o1, o1, a);
-  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
   WV_STAMP(1);
-  bool anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
-  WV_STAMP(2);
-  stage_L_and_logdet(a, anybad, o / NB);
+  factor_L_and_logdet(a, o / NB);
   WV_STAMP(3);
   invert64<W>(L, X, T, tid);  // X = M11
   WV_STAMP(4);
@@ -505,10 +535,7 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
   WV_STAMP(7);
 
   // ---- Schur complement: factor, invert -> M22 ----
-  for (int q = tid; q < NB * DS; q += 256) X[q] = 0;
-  anybad = factor64b<W>(a, dinfo, pbuf, ty, tx);
-  WV_STAMP(8);
-  stage_L_and_logdet(a, anybad, o / NB + 1);
+  factor_L_and_logdet(a, o / NB + 1);
   WV_STAMP(9);
   invert64<W>(L, X, T, tid);  // X = M22
   WV_STAMP(10);
