@@ -263,6 +263,33 @@ def test_non_positive_definite_reports_inf(ctx):
     prob.close()
 
 
+def test_a_bad_pivot_late_in_one_fit_leaves_the_other_fits_alone(ctx):
+    """An indefinite K_y whose FIRST pivots are fine (rank-one Lin Gram + a small negative noise: the pivot of some later
+    column goes non-positive inside a leaf, N = 300 -> three leaves) is flagged and reported as -inf / +inf; the fit
+    beside it in the batch returns exactly what it returns alone (the failed pivot is replaced by 1 inside the leaf, the
+    pipeline keeps running on finite numbers)."""
+    from waveome_amd.engine import Problem
+
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(300, 1)) + 3.0
+    Y = rng.normal(size=(300, 2))
+    ms = ModelSpec(K.Lin(active_dims=[0]), 1)
+    prob = Problem(ctx, X, Y, ms, max_batch=2)
+    good = ms.theta()
+    bad = good.copy()
+    bad[ms.noise] = -1e-3
+    alone, st_alone = prob.lml([0], good[None, :])
+    lml, st = prob.lml([0, 1], np.stack([good, bad]))
+    assert list(st) == [0, 1] and lml[1] == -np.inf and st_alone[0] == 0
+    assert lml[0] == alone[0]
+    u = ms.unconstrain()
+    f1, g1, s1 = prob.value_grad(np.array([0], dtype=np.int32), u[None, :])
+    # (value_grad takes unconstrained parameters: the noise cannot go negative there - the batch-mate is the same good fit)
+    f2, g2, s2 = prob.value_grad(np.array([0, 1], dtype=np.int32), np.stack([u, u]))
+    assert s1[0] == 0 and list(s2) == [0, 0] and f2[0] == f1[0] and np.array_equal(g2[0], g1[0])
+    prob.close()
+
+
 # ---------------------------------------------------------------- fits
 def test_fit_reproduces_reference_known_answers(ctx, golden_dir):
     from waveome_amd.engine import Problem, lbfgs_opts

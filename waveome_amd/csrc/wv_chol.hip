@@ -172,6 +172,13 @@ __device__ inline void mma_store(const double (&acc)[NA][NC][NR], R* __restrict_
 //   Pan: 4096 doubles of scratch ([column][row]).  Called by all 256 threads; returns "this wave saw a non-positive / NaN pivot".
 // ---------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) double lds_f64;  // (LDS pointers as such: constant offsets fold into ds_* offset fields)
+// 1 / sqrt(x) for finite x > 0: v_rsq_f64 and the one correction step of the library's rsqrt (same bits) without its
+// fix-up of zero / infinite arguments - four instructions off the pivot chain (the caller has excluded those arguments)
+__device__ inline double rsq_pos(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
 __device__ inline double lane_bcast(double v, int src) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src);
@@ -219,12 +226,15 @@ __device__ __forceinline__ void factor64c_step(double (&a)[4][4], lds_f64* __res
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int J = 4 * JB + c;
-      double piv = lane_bcast(a[Q][c], J);
-      const bool ok = piv > 0.0;  // false for NaN as well
-      piv = ok ? piv : 1.0;
+      const double piv = lane_bcast(a[Q][c], J);
+      const bool ok = piv > 0.0 && piv <= 1.7976931348623157e308;  // false for NaN; an overflowed pivot counts as bad too
+      // (branch-free, and the test runs beside the rsqrt instead of in front of it: a bad pivot is replaced by 1 - the
+      //  pipeline keeps running on finite numbers - by selecting this column's results at the end)
+      const double r0 = rsq_pos(piv);
+      const double alt = (lane == J) ? 1.0 : a[Q][c];
+      const double lj = ok ? a[Q][c] * r0 : alt;
+      const double ri = ok ? r0 : 1.0;
       anybad |= !ok;
-      const double ri = rsq(piv);
-      const double lj = (lane == J) ? piv * ri : a[Q][c] * ri;
       a[Q][c] = lj;
       rinv[J] = ri;  // (the same value from every lane)
 #pragma unroll
@@ -391,11 +401,11 @@ __global__ __launch_bounds__(256, 2) void potrf_diag_kernel(R* __restrict__ Kall
   __syncthreads();
   diag_inverses_L<W>(L, rinv, X, tid);
   __syncthreads();
-  if (tid < 64) {
-    double v = log((double)L[tid * DS + tid]);
+  if (tid >= 192) {  // (the last wave: see potrf128_kernel)
+    double v = log((double)L[(tid - 192) * DS + tid - 192]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (tid == 0) {
+    if (tid == 192) {
       logdet[(int64_t)b * nblk + j0 / NB] = v;
       if (bad) status[b] = 1;
     }
@@ -458,11 +468,11 @@ __global__ __launch_bounds__(256, 2) void potrf128_kernel(R* __restrict__ Kall, 
     if (blk & 1) WV_STAMP(8); else WV_STAMP(2);
     diag_inverses_L<W>(L, rinv, X, tid);
     __syncthreads();
-    if (tid < 64) {
-      double v = log((double)L[tid * DS + tid]);
+    if (tid >= 192) {  // (the last wave: it has no element of the inversion's first level, which the others start meanwhile)
+      double v = log((double)L[(tid - 192) * DS + tid - 192]);
 #pragma unroll
       for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
-      if (tid == 0) logdet[(int64_t)b * nblk + blk] = v;
+      if (tid == 192) logdet[(int64_t)b * nblk + blk] = v;
     }
   };
   auto write_inverse_block = [&](int64_t row0, int64_t col0) {  // X -> M[row0.., col0..] and its transpose into M'
