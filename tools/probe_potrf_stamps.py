@@ -24,13 +24,12 @@ lib = ctypes.CDLL(os.environ["WAVEOME_AMD_LIB"])
 out = (ctypes.c_ulonglong * 32)()
 assert lib.wv_dbg_stamps(out) == 0
 s = np.array(list(out), dtype=np.int64)
-names = {1: "load A11", 2: "stage + factor64c (A11) + clear X", 3: "4x4 inverses, log-det", 4: "invert64 (M11)", 5: "write M11 / M11'",
-         6: "S = A21 M11' (+ staging)", 7: "A22 -= S S', T2 = S M11", 8: "stage + factor64c (Schur) + clear X", 9: "4x4 inverses, log-det",
+names = {1: "load A11", 2: "stage + factor64c (A11) + clear X", 3: "16x16 diagonal inverses (wave 0) beside the log-det (wave 3)", 4: "invert64 (M11)", 5: "write M11 / M11'",
+         6: "S = A21 M11' (+ staging)", 7: "A22 -= S S', T2 = S M11", 8: "stage + factor64c (Schur) + clear X", 9: "16x16 diagonal inverses beside the log-det",
          10: "invert64 (M22)", 11: "write M22 / M22'", 12: "M21 = -M22 T2, stores"}
 tot = s[12] - s[0]
 print(f"potrf128, one workgroup, last node of an evaluation at N = {N}: {tot} shader-clock ticks")
 for i in range(1, 13):
     print(f"  {names[i]:32s} {s[i] - s[i - 1]:8d}  {100.0 * (s[i] - s[i - 1]) / tot:5.1f} %")
-inv = [s[16] - s[9], s[17] - s[16], s[18] - s[17], s[19] - s[18], s[10] - s[19]]
-print("  inside the second invert64: 4x4 blocks %d, level 4: %d, 8: %d, 16: %d, 32: %d" % tuple(inv))
+print("  inside the second invert64 (after the one-wave 16 x 16 diagonal inverses): level 16: %d, level 32: %d" % (s[19] - s[18], s[10] - s[19]))
 prob.close()
