@@ -532,6 +532,7 @@ static int32_t create_from_specs(Ctx* ctx, const double* X, int64_t N, int32_t D
             alloc((void**)&p.dcol, sizeof(int32_t) * max_batch) &&
             alloc((void**)&p.dstatus, sizeof(int32_t) * max_batch);
   if (ok && Np <= 2048 && !p.f32) ok = alloc((void**)&p.dsolve_part, sizeof(double) * (Np / 64) * Np * max_batch);
+  else if (ok && !p.f32) ok = alloc((void**)&p.dsolve_part, sizeof(double) * 8 * Np * max_batch);  // (TRMV_SLABS partial alphas)
   if (ok && p.f32) ok = alloc((void**)&p.df32r, sizeof(double) * F32R_VECS * Np * max_batch);
   if (!ok) {
     set_error("device allocation failed (workspace for max_batch fits does not fit in HBM)");

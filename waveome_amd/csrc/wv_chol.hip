@@ -600,8 +600,9 @@ void launch_resid(Problem& p, hipStream_t st, int slot0, int nb) {
                      p.dstatus, p.N, p.Npad, slot0, p.dmask);
 }
 
-// z = M r  (M lower triangular). One wave per row, 4 rows per wave, 16 rows per workgroup.
-template <typename R>
+// z = M r  (M lower triangular). One wave per row, RPW rows per wave (4; 1 with few fits in flight: four times the
+// workgroups, the same sums), 4 RPW rows per workgroup.
+template <typename R, int RPW = 4>
 __global__ __launch_bounds__(256) void trmv_kernel(const R* __restrict__ Mall,
                                                    const double* __restrict__ rall,
                                                    double* __restrict__ zall, int64_t Npad,
@@ -610,8 +611,8 @@ __global__ __launch_bounds__(256) void trmv_kernel(const R* __restrict__ Mall,
   const R* M = Mall + (int64_t)b * Npad * Npad;
   const double* r = rall + (int64_t)b * Npad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int rr = 0; rr < 4; ++rr) {
-    const int64_t i = (int64_t)blockIdx.x * 16 + wave * 4 + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int64_t i = (int64_t)blockIdx.x * (4 * RPW) + wave * RPW + rr;
     const R* row = M + i * Npad;
     double s = 0.0;
     const int64_t len = i + 1;  // columns 0..i
@@ -645,6 +646,40 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const R* __restrict__ Mall,
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0) aall[(int64_t)b * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// alpha = M' z above Npad = 2048 (where the one-pass kernel below has no registers for a row): the rows under a block of
+// 64 columns in TRMV_SLABS slabs, one workgroup each - with ONE fit in flight trmv_t_kernel's 64 workgroups walked 4 096
+// rows each (78 us at N = 4096); partial sums in a fixed place, summed in a fixed order (alpha_slab_reduce_kernel): the
+// result does not depend on how many fits share the launch.
+constexpr int TRMV_SLABS = 8;
+__global__ __launch_bounds__(256) void trmv_t_slab_kernel(const double* __restrict__ Mall, const double* __restrict__ zall,
+                                                          double* __restrict__ part, int64_t Npad, int slot0) {
+  __shared__ double red[4][64];
+  const int b = slot0 + blockIdx.y;
+  const double* M = Mall + (int64_t)b * Npad * Npad;
+  const double* z = zall + (int64_t)b * Npad;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cb = blockIdx.x / TRMV_SLABS, sl = blockIdx.x % TRMV_SLABS;
+  const int64_t j0 = (int64_t)cb * 64;
+  const int64_t rows = Npad - j0, per = (rows / TRMV_SLABS + 3) / 4 * 4;  // (a multiple of 4: every wave the same count)
+  const int64_t i0 = j0 + sl * per, i1 = min(Npad, i0 + per);
+  double s = 0.0;
+#pragma unroll 4
+  for (int64_t i = i0 + wave; i < i1; i += 4) s += M[i * Npad + j0 + lane] * z[i];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0)
+    part[((int64_t)b * TRMV_SLABS + sl) * Npad + j0 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void alpha_slab_reduce_kernel(const double* __restrict__ part, double* __restrict__ aall, int64_t Npad, int slot0) {
+  const int b = slot0 + blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Npad) return;
+  double s = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < TRMV_SLABS; ++sl) s += part[((int64_t)b * TRMV_SLABS + sl) * Npad + j];
+  aall[(int64_t)b * Npad + j] = s;
 }
 
 // One pass over M for both solves (Npad <= 2048): a wave owns 16 consecutive rows; for row i it
@@ -790,11 +825,21 @@ void launch_solve(Problem& p, hipStream_t st, int slot0, int nb, bool need_alpha
     p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * ((double)p.Npad * (p.Npad + 1) / 2.0 + 2.0 * nrb * p.Npad / 2.0));
     return;
   }
-  hipLaunchKernelGGL(trmv_kernel<double>, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
-                     p.dz, p.Npad, slot0);
-  if (need_alpha)
+  if (nb * (p.Npad / 16) < 2048)  // few fits: a row per wave (the sums of a row are the same ones)
+    hipLaunchKernelGGL((trmv_kernel<double, 1>), dim3((unsigned)(p.Npad / 4), nb), dim3(256), 0, st, p.Mbuf, p.dr,
+                       p.dz, p.Npad, slot0);
+  else
+    hipLaunchKernelGGL(trmv_kernel<double>, dim3((unsigned)(p.Npad / 16), nb), dim3(256), 0, st, p.Mbuf, p.dr,
+                       p.dz, p.Npad, slot0);
+  if (need_alpha && p.dsolve_part) {
+    hipLaunchKernelGGL(trmv_t_slab_kernel, dim3((unsigned)(p.Npad / 64 * TRMV_SLABS), nb), dim3(256), 0, st, p.Mbuf, p.dz,
+                       p.dsolve_part, p.Npad, slot0);
+    hipLaunchKernelGGL(alpha_slab_reduce_kernel, dim3((unsigned)((p.Npad + 255) / 256), nb), dim3(256), 0, st,
+                       p.dsolve_part, p.dalpha, p.Npad, slot0);
+  } else if (need_alpha) {
     hipLaunchKernelGGL(trmv_t_kernel<double>, dim3((unsigned)(p.Npad / 64), nb), dim3(256), 0, st, p.Mbuf,
                        p.dz, p.dalpha, p.Npad, slot0);
+  }
   p.timer.end(st);
   p.timer.work(ST_SOLVE, 0.0, (double)nb * 8.0 * (double)p.Npad * (p.Npad + 1) / 2.0 * (need_alpha ? 2 : 1));
 }

@@ -202,7 +202,7 @@ struct Problem {
   bool any_multidim = false;      // some factor of some structure acts on more than one column
   bool any_product = false;       // some structure has a product term (or may get one: capacity for later structures)
   int spec_cap = 0;               // entries of the device structure table (>= specs.size(): wv_problem_add_spec)
-  double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048)
+  double *dsolve_part = nullptr;  // [max_batch][Npad/64][Npad] partial alphas of the fused solve (Npad <= 2048); [max_batch][8][Npad] above
   // float32 contexts only (the float64-grade value of a float32 evaluation, wv_chol.hip launch_f32_refine):
   // [max_batch][F32R_VECS][Npad]: probe v, Mt'v, K_y Mt'v, K_y alpha, E v, E zt, Mt'E v, Mt'E zt, K_y Mt'E v, K_y Mt'E zt,
   // E^2 v, E^2 zt, diag(Mt'Mt) in float64
