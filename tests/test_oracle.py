@@ -273,7 +273,7 @@ def test_low_rank_kernels_against_their_closed_form():
 def test_matern_family_against_the_state_space_likelihood(kind):
     """The Matern kernels against a derivation that shares nothing with the oracle: the Kalman-filter likelihood of
     the equivalent stochastic differential equation (tests/statespace_matern.py).  Matern-3/2 has no stored value
-    anywhere in the reference; this is its independent pin (Matern-1/2 and -5/2 also have KAT-3 / KAT-2)."""
+    anywhere in the reference (parity unpinned); this is its independent check (Matern-1/2 and -5/2 also have KAT-3 / KAT-2)."""
     import statespace_matern as S
 
     rng = np.random.default_rng(7)
@@ -338,7 +338,8 @@ def test_random_low_rank_structures_against_their_closed_form():
     """Seeded random sums of products over the kernels that have a finite feature map - SE (one and two columns),
     Periodic, Lin, Poly (degree 2, 3), Categorical, Constant - : the oracle's LML against the capacitance-matrix closed
     form (oracle/closed_forms.py::spec_closed_form; features of a product = row-wise Kronecker product).  Two
-    derivations, no shared code: what makes either wrong makes them disagree."""
+    derivations, no shared code: what makes either wrong makes them disagree.  (Poly and the value of a surviving
+    Product term have no stored answer in the reference - parity unpinned; this is their independent check.)"""
     from oracle import closed_forms as CF
     from waveome_amd import ModelSpec, kernels as K
 
